@@ -1,0 +1,94 @@
+/*
+ * blosc_oracle.h — CPU restatement of go-blosc's Shuffle + LZ4 hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under go-blosc_amd/ (the product) may
+ * include, link or call this.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, as the checker / reported baseline.
+ *
+ * Parity status
+ *   filters + frame layer : restated line-for-line from the reference's scalar
+ *                           Go (citations on every function).  The reference
+ *                           holds NO golden vectors for them;
+ *                           pinned here by hand-derived KATs (tests/golden/)
+ *                           and, in the build container only, by C-Blosc's
+ *                           independent byte-shuffle.
+ *   LZ4 block codec       : the arithmetic lives in github.com/pierrec/lz4/v4
+ *                           v4.1.23 (go.mod:7), which is NOT in /root/reference
+ *                           and not on this filesystem.  Decoder semantics
+ *                           restated from the module's published
+ *                           UncompressBlock; encoder is a greedy hash matcher
+ *                           in the same family.  Compressed BYTES: PARITY
+ *                           UNPINNED (no Go toolchain, no vectors).  What is
+ *                           pinned: every stream is a spec-valid LZ4 block
+ *                           (cross-checked with liblz4 1.9.3 where present)
+ *                           and round-trips through this decoder.
+ */
+#ifndef BLOSC_ORACLE_H
+#define BLOSC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes: one per Go sentinel (blosc.go:125-149); same values as include/hipblosc.h */
+#define OB_OK                        0
+#define OB_ERR_INVALID_DATA        (-1)  /* ErrInvalidData          blosc.go:127 */
+#define OB_ERR_INVALID_HEADER      (-2)  /* ErrInvalidHeader        blosc.go:130 */
+#define OB_ERR_INVALID_VERSION     (-3)  /* ErrInvalidVersion       blosc.go:133 */
+#define OB_ERR_INVALID_CODEC       (-4)  /* ErrInvalidCodec         blosc.go:136 */
+#define OB_ERR_SIZE_MISMATCH       (-5)  /* ErrSizeMismatch         blosc.go:139 */
+#define OB_ERR_DATA_TOO_LARGE      (-6)  /* ErrDataTooLarge         blosc.go:142 */
+#define OB_ERR_COMPRESSION_FAILED  (-7)  /* ErrCompressionFailed    blosc.go:145 */
+#define OB_ERR_DECOMPRESSION_FAILED (-8) /* ErrDecompressionFailed  blosc.go:148 */
+#define OB_ERR_SHORT_BUFFER        (-12) /* caller's dst too small (C-side only) */
+
+/* enums, blosc.go:57-64 and :89-93 */
+enum { OB_BLOSCLZ = 0, OB_LZ4 = 1, OB_LZ4HC = 2, OB_SNAPPY = 3, OB_ZLIB = 4, OB_ZSTD = 5 };
+enum { OB_NOSHUFFLE = 0, OB_SHUFFLE = 1, OB_BITSHUFFLE = 2 };
+/* flag bits, blosc.go:110-115 */
+enum { OB_FLAG_SHUFFLE = 1, OB_FLAG_MEMCPY = 2, OB_FLAG_BITSHUFFLE = 4, OB_FLAG_SPLIT = 8 };
+#define OB_HEADER_SIZE 16
+
+/* compress-side policy bits (C-side only) */
+#define OB_POLICY_REFERENCE_MEMCPY 1u /* memcpy frames store the UN-filtered input, exactly as blosc.go:342-345 */
+
+typedef struct {
+    uint8_t  version, codec, flags, typesize;
+    uint32_t nbytes, blocksize, cbytes;
+} ob_header;
+
+/* ---- filters (shuffle.go) : dst and src must not overlap, both n bytes ---- */
+void ob_shuffle(uint8_t *dst, const uint8_t *src, size_t n, int typesize);      /* shuffle.go:16-73   */
+void ob_unshuffle(uint8_t *dst, const uint8_t *src, size_t n, int typesize);    /* shuffle.go:76-133  */
+void ob_bitshuffle(uint8_t *dst, const uint8_t *src, size_t n, int typesize);   /* shuffle.go:145-219 */
+void ob_bitunshuffle(uint8_t *dst, const uint8_t *src, size_t n, int typesize); /* shuffle.go:222-295 */
+/* op: 0 shuffle, 1 unshuffle, 2 bitshuffle, 3 bitunshuffle */
+void ob_filter(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize);
+
+/* ---- LZ4 block codec (codec.go:59-84 -> pierrec/lz4 v4.1.23) ---- */
+size_t  ob_lz4_bound(size_t n);                                                     /* codec.go:65 */
+int64_t ob_lz4_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap);    /* codec.go:66 */
+int64_t ob_lz4_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap);  /* codec.go:79 */
+
+/* ---- frame layer (blosc.go) ---- */
+int     ob_parse_header(const uint8_t *frame, size_t n, ob_header *h);              /* blosc.go:165-185 */
+void    ob_header_bytes(const ob_header *h, uint8_t out[16]);                       /* blosc.go:188-198 */
+size_t  ob_frame_bound(size_t n);
+int64_t ob_compress_frame(const uint8_t *src, size_t n, uint8_t *dst, size_t cap,
+                          int codec, int level, int shuffle, int typesize,
+                          unsigned policy);                                         /* blosc.go:268-374 */
+int64_t ob_decompress_frame(const uint8_t *frame, size_t n, uint8_t *dst, size_t cap,
+                            int typesize_override);                                 /* blosc.go:296-303, :377-434 */
+
+/* ---- synthetic workloads (bit-reproducible integer / exact-float arithmetic) ---- */
+enum { OB_D_F32 = 0, OB_D_F64 = 1, OB_D_I32 = 2, OB_D_RAMP = 3, OB_D_RAND = 4, OB_D_BYTES256 = 5 };
+/* fills `count` elements starting at element index `first` of frame `frame`; returns bytes written */
+size_t ob_synth(int kind, uint64_t frame, uint64_t first, uint64_t count, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
