@@ -1,0 +1,406 @@
+// hb_api.hip — the C ABI of include/hipblosc.h: device bookkeeping, cached device workspaces,
+// host-pointer entry points (stage H2D -> kernels -> D2H) and the thin `_dev` wrappers.
+// No CPU fallback anywhere: without a HIP device every compute entry point fails loudly.
+#include "hb_common.h"
+#include "hb_lz4.h"
+
+#include <mutex>
+#include <vector>
+#include <algorithm>
+#include <thread>
+#include <cstring>
+
+namespace {
+
+std::once_flag g_once;
+int g_ndev = 0;
+
+void do_init() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    g_ndev = n;
+}
+
+// ---- grow-only cache of device buffers, per device (hipMalloc/hipFree cost milliseconds) ----
+struct Buf { void *p; size_t bytes; int dev; };
+std::mutex g_pool_mu;
+std::vector<Buf> g_free;
+
+void *pool_get(int dev, size_t bytes, size_t *got) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_free.size(); i++)
+            if (g_free[i].dev == dev && g_free[i].bytes >= bytes && (best < 0 || g_free[i].bytes < g_free[best].bytes)) best = i;
+        if (best >= 0) {
+            Buf b = g_free[best];
+            g_free.erase(g_free.begin() + best);
+            *got = b.bytes;
+            return b.p;
+        }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    *got = bytes;
+    return p;
+}
+void pool_put(int dev, void *p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_free.push_back(Buf{p, bytes, dev});
+}
+
+struct Scratch {     // RAII over pool buffers for one host-API call
+    int dev;
+    std::vector<std::pair<void *, size_t>> held;
+    explicit Scratch(int d) : dev(d) {}
+    uint8_t *get(size_t bytes) {
+        size_t got = 0;
+        void *p = pool_get(dev, bytes, &got);
+        if (p) held.push_back({p, got});
+        return (uint8_t *)p;
+    }
+    ~Scratch() { for (auto &h : held) pool_put(dev, h.first, h.second); }
+};
+
+int select_device(int device) {
+    std::call_once(g_once, do_init);
+    if (g_ndev <= 0) return HB_ERR_NO_DEVICE;
+    if (device < 0 || device >= g_ndev) return HB_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return HB_ERR_HIP;   // device is per-thread state
+    return HB_OK;
+}
+
+bool overlap(const void *a, size_t na, const void *b, size_t nb) {
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return x < y + nb && y < x + na;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hb_init(void) {
+    std::call_once(g_once, do_init);
+    return g_ndev > 0 ? HB_OK : HB_ERR_NO_DEVICE;
+}
+
+int hb_device_count(void) {
+    std::call_once(g_once, do_init);
+    return g_ndev;
+}
+
+void hb_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &b : g_free) {
+        if (hipSetDevice(b.dev) == hipSuccess) (void)hipFree(b.p);
+    }
+    g_free.clear();
+}
+
+const char *hb_version(void) { return HB_VERSION_STRING; }
+
+const char *hb_strerror(int code) {
+    switch (code) {
+    case HB_OK: return "ok";
+    case HB_ERR_INVALID_DATA: return "blosc: invalid compressed data";            // blosc.go:127
+    case HB_ERR_INVALID_HEADER: return "blosc: invalid header";                   // blosc.go:130
+    case HB_ERR_INVALID_VERSION: return "blosc: unsupported format version";      // blosc.go:133
+    case HB_ERR_INVALID_CODEC: return "blosc: unsupported codec";                 // blosc.go:136
+    case HB_ERR_SIZE_MISMATCH: return "blosc: decompressed size mismatch";        // blosc.go:139
+    case HB_ERR_DATA_TOO_LARGE: return "blosc: data too large";                   // blosc.go:142
+    case HB_ERR_COMPRESSION_FAILED: return "blosc: compression failed";           // blosc.go:145
+    case HB_ERR_DECOMPRESSION_FAILED: return "blosc: decompression failed";       // blosc.go:148
+    case HB_ERR_NO_DEVICE: return "hipblosc: no HIP device";
+    case HB_ERR_HIP: return "hipblosc: HIP runtime error";
+    case HB_ERR_BAD_ARG: return "hipblosc: bad argument";
+    case HB_ERR_SHORT_BUFFER: return "hipblosc: destination or workspace too small";
+    default: return "hipblosc: unknown error";
+    }
+}
+
+void *hb_host_alloc(size_t bytes) {
+    std::call_once(g_once, do_init);
+    if (g_ndev <= 0) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void hb_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// ------------------------------------------------------------------------------------------
+// filters
+// ------------------------------------------------------------------------------------------
+int hb_filter_dev(int op, void *d_dst, const void *d_src, size_t n, int typesize, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
+    if (n == 0) return HB_OK;
+    if (!d_dst || !d_src || overlap(d_dst, n, d_src, n)) return HB_ERR_BAD_ARG;
+    return hb_launch_filter(op, (uint8_t *)d_dst, (const uint8_t *)d_src, n, typesize, (hipStream_t)stream);
+}
+
+int hb_filter(int op, void *dst, const void *src, size_t n, int typesize, int device) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
+    if (n == 0) return HB_OK;
+    if (!dst || !src || overlap(dst, n, src, n)) return HB_ERR_BAD_ARG;
+    Scratch sc(device);
+    uint8_t *d_src = sc.get(n), *d_dst = sc.get(n);
+    if (!d_src || !d_dst) return HB_ERR_HIP;
+    HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
+    rc = hb_launch_filter(op, d_dst, d_src, n, typesize, nullptr);
+    if (rc) return rc;
+    HB_HIP_TRY(hipMemcpy(dst, d_dst, n, hipMemcpyDeviceToHost));   // synchronises with the null stream
+    return HB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LZ4 block codec
+// ------------------------------------------------------------------------------------------
+size_t hb_lz4_bound(size_t n) { return n + n / 255 + 16; }           // codec.go:65
+size_t hb_index_bound(size_t n) { return hb_lz4_index_bound(n); }
+size_t hb_lz4_compress_workspace(size_t n) { return hb_lz4_enc_workspace(n); }
+size_t hb_lz4_decompress_workspace(size_t n_out) { return hb_lz4_dec_workspace(n_out); }
+
+int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap, void *d_index, size_t index_cap,
+                        void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (!d_src || !d_dst || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if (n > 0xFFFFFFFFull - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
+    if (cap < hb_lz4_bound(n)) return HB_ERR_SHORT_BUFFER;
+    if (work_bytes < hb_lz4_enc_workspace(n)) return HB_ERR_SHORT_BUFFER;
+    if (d_index && index_cap < hb_lz4_index_bound(n)) return HB_ERR_SHORT_BUFFER;
+    hb_enc_args a{};
+    a.src = (const uint8_t *)d_src; a.n = n; a.dst = (uint8_t *)d_dst; a.cap = cap;
+    a.index = (uint8_t *)d_index; a.work = (uint8_t *)d_work; a.result = d_result;
+    a.frame = 0;
+    return hb_launch_lz4_encode(a, (hipStream_t)stream);
+}
+
+int hb_lz4_decompress_dev(const void *d_src, size_t n, void *d_dst, size_t cap, const void *d_index, size_t index_bytes,
+                          void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if ((!d_src && n) || (!d_dst && cap) || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if (work_bytes < hb_lz4_dec_workspace(cap)) return HB_ERR_SHORT_BUFFER;
+    hb_dec_args a{};
+    a.src = (const uint8_t *)d_src; a.n = n; a.dst = (uint8_t *)d_dst; a.cap = cap;
+    a.index = (const uint8_t *)d_index; a.index_bytes = index_bytes;
+    a.work = (uint8_t *)d_work; a.result = d_result; a.frame = 0;
+    return hb_launch_lz4_decode(a, (hipStream_t)stream);
+}
+
+int64_t hb_lz4_compress(const void *src, size_t n, void *dst, size_t cap, int device) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    if ((!src && n) || !dst) return HB_ERR_BAD_ARG;
+    if (n > 0xFFFFFFFFull - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
+    if (cap < hb_lz4_bound(n)) return HB_ERR_SHORT_BUFFER;
+    Scratch sc(device);
+    const size_t wb = hb_lz4_enc_workspace(n);
+    uint8_t *d_src = sc.get(n + 16), *d_dst = sc.get(hb_lz4_bound(n) + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_src || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
+    if (n) HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
+    rc = hb_lz4_compress_dev(d_src, n, d_dst, hb_lz4_bound(n) + 64, nullptr, 0, d_work, wb, (hb_result *)d_res, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;
+    if (r.bytes > cap) return HB_ERR_SHORT_BUFFER;
+    HB_HIP_TRY(hipMemcpy(dst, d_dst, r.bytes, hipMemcpyDeviceToHost));
+    return (int64_t)r.bytes;
+}
+
+int64_t hb_lz4_decompress(const void *src, size_t n, void *dst, size_t cap, int device) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    if ((!src && n) || (!dst && cap)) return HB_ERR_BAD_ARG;
+    if (n == 0) return 0;                                             // UncompressBlock: empty src -> 0, nil
+    Scratch sc(device);
+    const size_t wb = hb_lz4_dec_workspace(cap);
+    uint8_t *d_src = sc.get(n + 64), *d_dst = sc.get(cap + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_src || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
+    HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
+    rc = hb_lz4_decompress_dev(d_src, n, d_dst, cap, nullptr, 0, d_work, wb, (hb_result *)d_res, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;
+    if (r.bytes) HB_HIP_TRY(hipMemcpy(dst, d_dst, r.bytes, hipMemcpyDeviceToHost));
+    return (int64_t)r.bytes;
+}
+
+// ------------------------------------------------------------------------------------------
+// frame layer
+// ------------------------------------------------------------------------------------------
+static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+int hb_parse_header(const void *frame, size_t n, hb_header *h) {      // blosc.go:165-185
+    if (!h || (!frame && n)) return HB_ERR_BAD_ARG;
+    if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;
+    const uint8_t *f = (const uint8_t *)frame;
+    h->version = f[0]; h->codec = f[1]; h->flags = f[2]; h->typesize = f[3];
+    h->nbytes = le32(f + 4); h->blocksize = le32(f + 8); h->cbytes = le32(f + 12);
+    if (h->version != HB_FORMAT_VERSION) return HB_ERR_INVALID_VERSION;
+    return HB_OK;
+}
+
+void hb_header_bytes(const hb_header *h, void *out16) {               // blosc.go:188-198
+    uint8_t *o = (uint8_t *)out16;
+    o[0] = h->version; o[1] = h->codec; o[2] = h->flags; o[3] = h->typesize;
+    put32(o + 4, h->nbytes); put32(o + 8, h->blocksize); put32(o + 12, h->cbytes);
+}
+
+size_t hb_frame_bound(size_t n) { return HB_HEADER_SIZE + hb_lz4_bound(n) + 8 + hb_lz4_index_bound(n); }
+size_t hb_compress_frame_workspace(size_t n) { return hb_lz4_enc_workspace(n) + ((n + 255) & ~(size_t)255) + 256; }
+size_t hb_decompress_frame_workspace(size_t n_out) { return hb_lz4_dec_workspace(n_out) + ((n_out + 255) & ~(size_t)255) + 256; }
+
+int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap, int codec, int level, int shuffle,
+                          int typesize, unsigned opts, void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271
+    if (!d_src || !d_frame || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if (typesize <= 0) typesize = 1;                                  // blosc.go:274-276
+    if (level < 1) level = 1;                                         // blosc.go:277-279 (LZ4 ignores level, codec.go:63-66)
+    if (level > 9) level = 9;
+    (void)level;
+    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;                 // only the LZ4 codec is on the device path
+    if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
+    if (cap < hb_frame_bound(n)) return HB_ERR_SHORT_BUFFER;
+    if (work_bytes < hb_compress_frame_workspace(n)) return HB_ERR_SHORT_BUFFER;
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *work = (uint8_t *)d_work;
+    uint8_t *filtered = work;                                         // first n bytes (256-aligned size)
+    uint8_t *enc_work = work + ((n + 255) & ~(size_t)255) + 256;
+    const bool filt = (shuffle == HB_SHUFFLE || shuffle == HB_BITSHUFFLE) && typesize > 1;   // blosc.go:329-333
+    const uint8_t *in = (const uint8_t *)d_src;
+    if (filt) {
+        int rc = hb_launch_filter(shuffle == HB_SHUFFLE ? HB_OP_SHUFFLE : HB_OP_BITSHUFFLE, filtered,
+                                  (const uint8_t *)d_src, n, typesize, s);
+        if (rc) return rc;
+        in = filtered;
+    }
+    hb_enc_args a{};
+    a.src = in; a.n = n; a.dst = (uint8_t *)d_frame; a.cap = cap; a.index = nullptr;
+    a.work = enc_work; a.result = d_result;
+    a.frame = 1; a.codec = codec; a.shuffle = shuffle; a.typesize = typesize; a.opts = opts;
+    a.memcpy_src = (opts & HB_OPT_REFERENCE_MEMCPY) ? (const uint8_t *)d_src : in;   // blosc.go:343-345 vs Appendix D
+    return hb_launch_lz4_encode(a, s);
+}
+
+int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t cap, int typesize_override,
+                            void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;             // blosc.go:297-299
+    if (!d_frame || !d_work || !d_result || (!d_dst && cap)) return HB_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    // The launch shape of the un-filter depends on header fields: read the 16 header bytes back.
+    uint8_t hb[HB_HEADER_SIZE];
+    HB_HIP_TRY(hipMemcpyAsync(hb, d_frame, HB_HEADER_SIZE, hipMemcpyDeviceToHost, s));
+    HB_HIP_TRY(hipStreamSynchronize(s));
+    hb_header h;
+    int rc = hb_parse_header(hb, HB_HEADER_SIZE, &h);                 // blosc.go:379-382
+    if (rc) return rc;
+    if ((size_t)h.cbytes > n) return HB_ERR_INVALID_DATA;             // blosc.go:385-387
+    if (h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;        // blosc.go:388-390
+    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;  // :403-407
+    if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
+    if (work_bytes < hb_decompress_frame_workspace(h.nbytes)) return HB_ERR_SHORT_BUFFER;
+    const int ts = typesize_override > 0 ? typesize_override : (int)h.typesize;   // blosc.go:417-419
+    int unf = -1;
+    if ((h.flags & HB_FLAG_BITSHUFFLE) && ts > 1) unf = HB_OP_BITUNSHUFFLE;       // blosc.go:422-423 (bitshuffle wins)
+    else if ((h.flags & HB_FLAG_SHUFFLE) && ts > 1) unf = HB_OP_UNSHUFFLE;        // blosc.go:424-425
+    uint8_t *work = (uint8_t *)d_work;
+    uint8_t *staged = work;
+    uint8_t *dec_work = work + (((size_t)h.nbytes + 255) & ~(size_t)255) + 256;
+    uint8_t *target = (unf >= 0) ? staged : (uint8_t *)d_dst;
+    const uint8_t *payload = (const uint8_t *)d_frame + HB_HEADER_SIZE;
+    const size_t plen = h.cbytes - HB_HEADER_SIZE;
+    hb_dec_args a{};
+    a.src = payload; a.n = plen; a.dst = target; a.cap = h.nbytes;
+    a.work = dec_work; a.result = d_result; a.frame = 1; a.expect = h.nbytes;
+    a.memcpy_payload = (h.flags & HB_FLAG_MEMCPY) ? 1 : 0;            // blosc.go:398-400
+    // restart index, if any, sits after cbytes (ignored by the reference decoder, blosc.go:385-393)
+    const size_t ioff = ((size_t)h.cbytes + 7) & ~(size_t)7;
+    if (!a.memcpy_payload && n > ioff + 32) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }
+    rc = hb_launch_lz4_decode(a, s);
+    if (rc) return rc;
+    if (unf >= 0) {
+        // length check (blosc.go:429-431) is done on the device; the un-filter runs on nbytes bytes, as the
+        // reference would only get here with len == NBytesOrig or fail afterwards.
+        rc = hb_launch_filter(unf, (uint8_t *)d_dst, staged, h.nbytes, ts, s);
+        if (rc) return rc;
+    }
+    return HB_OK;
+}
+
+int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int codec, int level, int shuffle,
+                          int typesize, unsigned opts, int device) {
+    if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271 (before anything else)
+    int rc = select_device(device);
+    if (rc) return rc;
+    if (!src || !dst) return HB_ERR_BAD_ARG;
+    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;
+    if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
+    Scratch sc(device);
+    const size_t fb = hb_frame_bound(n), wb = hb_compress_frame_workspace(n);
+    uint8_t *d_src = sc.get(n + 16), *d_frame = sc.get(fb + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_src || !d_frame || !d_work || !d_res) return HB_ERR_HIP;
+    HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
+    rc = hb_compress_frame_dev(d_src, n, d_frame, fb + 64, codec, level, shuffle, typesize, opts, d_work, wb,
+                               (hb_result *)d_res, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;
+    const size_t out = (opts & HB_OPT_INDEX_TRAILER) ? r.total_bytes : r.bytes;
+    if (out > cap) return HB_ERR_SHORT_BUFFER;
+    HB_HIP_TRY(hipMemcpy(dst, d_frame, out, hipMemcpyDeviceToHost));
+    return (int64_t)out;
+}
+
+int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, int typesize_override, int device) {
+    if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;             // blosc.go:297-299
+    if (!frame) return HB_ERR_BAD_ARG;
+    hb_header h;
+    int rc = hb_parse_header(frame, n, &h);
+    if (rc) return rc;
+    if ((size_t)h.cbytes > n || h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;
+    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;
+    rc = select_device(device);
+    if (rc) return rc;
+    if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
+    Scratch sc(device);
+    const size_t wb = hb_decompress_frame_workspace(h.nbytes);
+    uint8_t *d_frame = sc.get(n + 64), *d_dst = sc.get((size_t)h.nbytes + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_frame || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
+    HB_HIP_TRY(hipMemcpy(d_frame, frame, n, hipMemcpyHostToDevice));
+    rc = hb_decompress_frame_dev(d_frame, n, d_dst, h.nbytes, typesize_override, d_work, wb, (hb_result *)d_res, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;
+    if (r.bytes) HB_HIP_TRY(hipMemcpy(dst, d_dst, r.bytes, hipMemcpyDeviceToHost));
+    return (int64_t)r.bytes;
+}
+
+int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *n, void *const *dst, const size_t *cap,
+                             int64_t *rc, int codec, int level, int shuffle, int typesize, unsigned opts) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (nframes < 0 || (nframes && (!src || !n || !dst || !cap || !rc))) return HB_ERR_BAD_ARG;
+    const int nd = g_ndev;
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd && d < nframes; d++) {
+        th.emplace_back([=]() {           // one host thread per device, frames k = d, d+nd, ...
+            for (int k = d; k < nframes; k += nd)
+                rc[k] = hb_compress_frame(src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts, d);
+        });
+    }
+    for (auto &t : th) t.join();
+    return HB_OK;
+}
+
+}  // extern "C"

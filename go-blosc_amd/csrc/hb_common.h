@@ -1,0 +1,62 @@
+// hb_common.h — shared device/host helpers for the gfx950 kernels (internal; not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/hipblosc.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// 16-/8-/4-byte accesses with no alignment promise.  gfx950 under amdhsa runs global memory in
+// unaligned access mode, so these lower to single global_load/store_dwordx4 / dwordx2 / dword.
+struct __attribute__((packed, aligned(1))) hb_u128u { u32x4 v; };
+struct __attribute__((packed, aligned(1))) hb_u64u { uint64_t v; };
+struct __attribute__((packed, aligned(1))) hb_u32u { uint32_t v; };
+
+__device__ __forceinline__ u32x4 ld16u(const uint8_t *p) { return ((const hb_u128u *)p)->v; }
+__device__ __forceinline__ void st16u(uint8_t *p, u32x4 v) { ((hb_u128u *)p)->v = v; }
+__device__ __forceinline__ uint64_t ld8u(const uint8_t *p) { return ((const hb_u64u *)p)->v; }
+__device__ __forceinline__ void st8u(uint8_t *p, uint64_t v) { ((hb_u64u *)p)->v = v; }
+__device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { return ((const hb_u32u *)p)->v; }
+__device__ __forceinline__ void st4u(uint8_t *p, uint32_t v) { ((hb_u32u *)p)->v = v; }
+
+// all lanes of the wave have finished their LDS traffic up to here, and the compiler may not
+// move LDS accesses across this point (single-wave producer/consumer through LDS).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 4x4 byte transpose: in e[i] = bytes of row i; out p[j] = {e0.bj, e1.bj, e2.bj, e3.bj}.  Involution.
+__device__ __forceinline__ void transpose4x4(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3,
+                                             uint32_t &p0, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    // v_perm_b32 D = bytes of {S0:S1}; selector 0-3 -> S1 (2nd arg), 4-7 -> S0 (1st arg)
+    const uint32_t t0 = __builtin_amdgcn_perm(e1, e0, 0x05010400u);  // e0.b0 e1.b0 e0.b1 e1.b1
+    const uint32_t t1 = __builtin_amdgcn_perm(e1, e0, 0x07030602u);  // e0.b2 e1.b2 e0.b3 e1.b3
+    const uint32_t t2 = __builtin_amdgcn_perm(e3, e2, 0x05010400u);
+    const uint32_t t3 = __builtin_amdgcn_perm(e3, e2, 0x07030602u);
+    p0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    p1 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    p3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+// 8x8 bit transpose in go-blosc's MSB-first convention (shuffle.go:192-200):
+// in byte e = B[e]; out byte k has bit (7-e) = bit (7-k) of B[e].  Involution.
+__device__ __forceinline__ uint64_t bit_transpose8x8_msb(uint64_t x) {
+    // MSB-first on both axes = the LSB-first transpose rotated by 180 degrees = a flip about the
+    // ANTI-diagonal of the 8x8 bit matrix (byte r, bit c) <-> (byte 7-c, bit 7-r): three masked
+    // swap steps with strides 9/18/36 (the main-diagonal transpose uses 7/14/28).
+    uint64_t t;
+    t = (x ^ (x >> 9)) & 0x0055005500550055ull;  x = x ^ t ^ (t << 9);
+    t = (x ^ (x >> 18)) & 0x0000333300003333ull; x = x ^ t ^ (t << 18);
+    t = (x ^ (x >> 36)) & 0x000000000F0F0F0Full; x = x ^ t ^ (t << 36);
+    return x;
+}
+
+#define HB_HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return HB_ERR_HIP; } while (0)
+
+// ---- internal launch API shared between translation units ----
+int hb_launch_filter(int op, uint8_t *d_dst, const uint8_t *d_src, size_t n, int typesize, hipStream_t s);

@@ -1,0 +1,266 @@
+// hb_filters.hip — byte-shuffle / unshuffle / bitshuffle / bitunshuffle for gfx950.
+//
+// Semantics: shuffle.go:16-73, :76-133, :145-219, :222-295 of the reference (scalar branches;
+// its AVX2/NEON paths produce identical bytes).  These are byte/bit PERMUTATIONS: HBM-bound,
+// 2*n algorithmic bytes, no MFMA.  Layout in HBM: src is the caller's AoS buffer, dst the
+// `typesize` byte planes of ne = n/typesize bytes each (tail n%typesize verbatim).
+//
+// Vector kernels (typesize 2/4/8/16): one wavefront owns a tile of 1024 elements.  Each lane
+// reads 16-byte vectors (coalesced), transposes 4 elements x 4 bytes in registers with v_perm_b32,
+// and parks one dword per plane in a wave-private LDS slab; the slab is then read back as one
+// ds_read_b128 per plane and stored with 16 B per lane = 1 KiB contiguous per plane per
+// instruction.  No workgroup barrier: a wave only ever reads its own slab.
+// Generic kernels (any typesize, ragged ends) are byte-granular and finish what the tiles leave.
+#include "hb_common.h"
+
+#define TILE_ELEMS 1024
+
+// ----------------------------------------------------------------------------------------------
+// byte shuffle / unshuffle, vector path
+// ----------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                     uint64_t ne, uint64_t ntiles) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[4][TS][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t(*my)[256] = slab[wave];
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
+        const uint64_t e0 = tile * TILE_ELEMS;
+        if constexpr (TS == 2) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {       // 8 elements (16 B) per lane per step
+                const u32x4 v = ld16u(src + (e0 + (uint64_t)it * 512 + lane * 8) * 2);
+                u32x2 p0, p1;
+                p0.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u); p1.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
+                p0.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u); p1.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
+                *(u32x2 *)&my[0][it * 128 + lane * 2] = p0;
+                *(u32x2 *)&my[1][it * 128 + lane * 2] = p1;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {       // 4 elements (4*TS bytes) per lane per step
+                const uint8_t *p = src + (e0 + (uint64_t)it * 256 + lane * 4) * TS;
+                uint32_t w[TS];                    // w[e*TS/4 + q] = dword q of element e
+#pragma unroll
+                for (int q = 0; q < TS / 4; q++) {
+                    const u32x4 v = ld16u(p + q * 16);
+                    w[q * 4 + 0] = v.x; w[q * 4 + 1] = v.y; w[q * 4 + 2] = v.z; w[q * 4 + 3] = v.w;
+                }
+#pragma unroll
+                for (int q = 0; q < TS / 4; q++) { // byte planes 4q .. 4q+3
+                    uint32_t p0, p1, p2, p3;
+                    transpose4x4(w[0 * (TS / 4) + q], w[1 * (TS / 4) + q], w[2 * (TS / 4) + q], w[3 * (TS / 4) + q],
+                                 p0, p1, p2, p3);
+                    my[4 * q + 0][it * 64 + lane] = p0;
+                    my[4 * q + 1][it * 64 + lane] = p1;
+                    my[4 * q + 2][it * 64 + lane] = p2;
+                    my[4 * q + 3][it * 64 + lane] = p3;
+                }
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < TS; j++) {
+            const u32x4 v = *(const u32x4 *)&my[j][lane * 4];
+            st16u(dst + (uint64_t)j * ne + e0 + lane * 16, v);
+        }
+        wave_sync();
+    }
+}
+
+template <int TS>
+__global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                       uint64_t ne, uint64_t ntiles) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[4][TS][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t(*my)[256] = slab[wave];
+    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
+        const uint64_t e0 = tile * TILE_ELEMS;
+#pragma unroll
+        for (int j = 0; j < TS; j++)
+            *(u32x4 *)&my[j][lane * 4] = ld16u(src + (uint64_t)j * ne + e0 + lane * 16);
+        wave_sync();
+        if constexpr (TS == 2) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const u32x2 p0 = *(const u32x2 *)&my[0][it * 128 + lane * 2];
+                const u32x2 p1 = *(const u32x2 *)&my[1][it * 128 + lane * 2];
+                u32x4 v;                            // element e = {p0.byte e, p1.byte e}
+                v.x = __builtin_amdgcn_perm(p1.x, p0.x, 0x05010400u); v.y = __builtin_amdgcn_perm(p1.x, p0.x, 0x07030602u);
+                v.z = __builtin_amdgcn_perm(p1.y, p0.y, 0x05010400u); v.w = __builtin_amdgcn_perm(p1.y, p0.y, 0x07030602u);
+                st16u(dst + (e0 + (uint64_t)it * 512 + lane * 8) * 2, v);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                uint32_t w[TS];
+#pragma unroll
+                for (int q = 0; q < TS / 4; q++) {
+                    uint32_t e0_, e1_, e2_, e3_;
+                    transpose4x4(my[4 * q + 0][it * 64 + lane], my[4 * q + 1][it * 64 + lane],
+                                 my[4 * q + 2][it * 64 + lane], my[4 * q + 3][it * 64 + lane], e0_, e1_, e2_, e3_);
+                    w[0 * (TS / 4) + q] = e0_; w[1 * (TS / 4) + q] = e1_; w[2 * (TS / 4) + q] = e2_; w[3 * (TS / 4) + q] = e3_;
+                }
+                uint8_t *p = dst + (e0 + (uint64_t)it * 256 + lane * 4) * TS;
+#pragma unroll
+                for (int q = 0; q < TS / 4; q++) {
+                    u32x4 v; v.x = w[q * 4 + 0]; v.y = w[q * 4 + 1]; v.z = w[q * 4 + 2]; v.w = w[q * 4 + 3];
+                    st16u(p + q * 16, v);
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// byte shuffle / unshuffle, generic path: elements [e_begin, e_end) of every plane + the tail bytes
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                         uint64_t n, uint64_t ne, uint32_t ts,
+                                                         uint64_t e_begin, int inverse) {
+    const uint64_t cnt = ne - e_begin, total = cnt * ts, tail0 = ne * ts;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        if (!inverse) {                 // idx walks the planes: coalesced stores   (shuffle.go:62)
+            const uint64_t j = idx / cnt, i = e_begin + idx % cnt;
+            dst[j * ne + i] = src[i * ts + j];
+        } else {                        // idx walks the elements: coalesced stores (shuffle.go:122)
+            const uint64_t i = e_begin + idx / ts, j = idx % ts;
+            dst[i * ts + j] = src[j * ne + i];
+        }
+    }
+    for (uint64_t t = tail0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+        dst[t] = src[t];                // shuffle.go:67-70 / :127-130
+}
+
+// ----------------------------------------------------------------------------------------------
+// bitshuffle / bitunshuffle
+// ----------------------------------------------------------------------------------------------
+// typesize 4: one lane owns one group of 8 elements = one 32-byte window (in and out).
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void k_bitshuffle4(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                     uint64_t ngroups) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
+        const u32x4 a = ld16u(src + g * 32), b = ld16u(src + g * 32 + 16);
+        u32x4 oa, ob;
+        if (!INVERSE) {
+            // gather byte position bp of the 8 elements -> 8 bytes, bit-transpose, store at window + 8*bp
+            uint32_t l0, l1, l2, l3, h0, h1, h2, h3;
+            transpose4x4(a.x, a.y, a.z, a.w, l0, l1, l2, l3);   // l[bp] = byte bp of elements 0..3
+            transpose4x4(b.x, b.y, b.z, b.w, h0, h1, h2, h3);   // h[bp] = byte bp of elements 4..7
+            const uint64_t y0 = bit_transpose8x8_msb(((uint64_t)h0 << 32) | l0);
+            const uint64_t y1 = bit_transpose8x8_msb(((uint64_t)h1 << 32) | l1);
+            const uint64_t y2 = bit_transpose8x8_msb(((uint64_t)h2 << 32) | l2);
+            const uint64_t y3 = bit_transpose8x8_msb(((uint64_t)h3 << 32) | l3);
+            oa.x = (uint32_t)y0; oa.y = (uint32_t)(y0 >> 32); oa.z = (uint32_t)y1; oa.w = (uint32_t)(y1 >> 32);
+            ob.x = (uint32_t)y2; ob.y = (uint32_t)(y2 >> 32); ob.z = (uint32_t)y3; ob.w = (uint32_t)(y3 >> 32);
+        } else {
+            // 8 bytes at window + 8*bp -> transpose -> byte e goes to element e, byte position bp
+            const uint64_t y0 = bit_transpose8x8_msb(((uint64_t)a.y << 32) | a.x);
+            const uint64_t y1 = bit_transpose8x8_msb(((uint64_t)a.w << 32) | a.z);
+            const uint64_t y2 = bit_transpose8x8_msb(((uint64_t)b.y << 32) | b.x);
+            const uint64_t y3 = bit_transpose8x8_msb(((uint64_t)b.w << 32) | b.z);
+            uint32_t e0, e1, e2, e3, e4, e5, e6, e7;
+            transpose4x4((uint32_t)y0, (uint32_t)y1, (uint32_t)y2, (uint32_t)y3, e0, e1, e2, e3);
+            transpose4x4((uint32_t)(y0 >> 32), (uint32_t)(y1 >> 32), (uint32_t)(y2 >> 32), (uint32_t)(y3 >> 32),
+                         e4, e5, e6, e7);
+            oa.x = e0; oa.y = e1; oa.z = e2; oa.w = e3; ob.x = e4; ob.y = e5; ob.z = e6; ob.w = e7;
+        }
+        st16u(dst + g * 32, oa);
+        st16u(dst + g * 32 + 16, ob);
+    }
+}
+
+// any typesize: one thread per (group, byte position).  shuffle.go:184-200 / :261-277
+__global__ __launch_bounds__(256) void k_bitshuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                            uint64_t n, uint64_t ngroups, uint32_t ts, int inverse,
+                                                            uint64_t g_begin) {
+    const uint64_t total = ngroups * ts, done = ngroups * 8 * ts;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = g_begin * ts + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const uint64_t g = idx / ts, bp = idx % ts, base = g * 8 * ts;
+        uint64_t x = 0;
+        if (!inverse) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x |= (uint64_t)src[base + (uint64_t)e * ts + bp] << (8 * e);
+            const uint64_t y = bit_transpose8x8_msb(x);
+#pragma unroll
+            for (int k = 0; k < 8; k++) dst[base + bp * 8 + k] = (uint8_t)(y >> (8 * k));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) x |= (uint64_t)src[base + bp * 8 + i] << (8 * i);
+            const uint64_t y = bit_transpose8x8_msb(x);
+#pragma unroll
+            for (int e = 0; e < 8; e++) dst[base + (uint64_t)e * ts + bp] = (uint8_t)(y >> (8 * e));
+        }
+    }
+    for (uint64_t t = done + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
+        dst[t] = src[t];                // leftover elements + tail bytes, shuffle.go:206-216 / :282-292
+}
+
+// ----------------------------------------------------------------------------------------------
+// launch
+// ----------------------------------------------------------------------------------------------
+static inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap_blocks) {
+    uint64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap_blocks) b = cap_blocks;
+    return (unsigned)b;
+}
+
+template <int TS>
+static void launch_shuffle_vec(bool inverse, uint8_t *dst, const uint8_t *src, uint64_t ne, uint64_t ntiles, hipStream_t s) {
+    const unsigned grid = grid_for(ntiles, 4, 256 * 8);
+    if (!inverse) hipLaunchKernelGGL(k_shuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles);
+    else hipLaunchKernelGGL(k_unshuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles);
+}
+
+int hb_launch_filter(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, hipStream_t s) {
+    if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
+    if (n == 0) return HB_OK;
+    if (typesize <= 1 || n < (size_t)typesize) {        // shuffle.go:17-19 etc.: identity
+        HB_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+        return HB_OK;
+    }
+    const uint64_t ts = (uint64_t)typesize, ne = n / ts;
+    if (op == HB_OP_SHUFFLE || op == HB_OP_UNSHUFFLE) {
+        const bool inv = (op == HB_OP_UNSHUFFLE);
+        uint64_t ntiles = 0;
+        if (ts == 2 || ts == 4 || ts == 8 || ts == 16) {
+            ntiles = ne / TILE_ELEMS;
+            if (ntiles) {
+                switch (ts) {
+                case 2: launch_shuffle_vec<2>(inv, dst, src, ne, ntiles, s); break;
+                case 4: launch_shuffle_vec<4>(inv, dst, src, ne, ntiles, s); break;
+                case 8: launch_shuffle_vec<8>(inv, dst, src, ne, ntiles, s); break;
+                default: launch_shuffle_vec<16>(inv, dst, src, ne, ntiles, s); break;
+                }
+            }
+        }
+        const uint64_t e_begin = ntiles * TILE_ELEMS;
+        if (e_begin < ne || ne * ts < n) {
+            const uint64_t items = (ne - e_begin) * ts + (n - ne * ts);
+            hipLaunchKernelGGL(k_shuffle_generic, dim3(grid_for(items, 256, 256 * 16)), dim3(256), 0, s,
+                               dst, src, (uint64_t)n, ne, (uint32_t)ts, e_begin, inv ? 1 : 0);
+        }
+    } else {
+        const bool inv = (op == HB_OP_BITUNSHUFFLE);
+        const uint64_t ng = ne / 8;
+        if (ts == 4 && ng > 0) {
+            const unsigned grid = grid_for(ng, 256, 256 * 16);
+            if (!inv) hipLaunchKernelGGL(k_bitshuffle4<false>, dim3(grid), dim3(256), 0, s, dst, src, ng);
+            else hipLaunchKernelGGL(k_bitshuffle4<true>, dim3(grid), dim3(256), 0, s, dst, src, ng);
+            if (ng * 32 < n)   // leftover elements + tail bytes only (g_begin = ng: no groups)
+                hipLaunchKernelGGL(k_bitshuffle_generic, dim3(1), dim3(256), 0, s, dst, src, (uint64_t)n, ng, 4u,
+                                   inv ? 1 : 0, ng);
+        } else {
+            const uint64_t items = ng * ts + (n - ng * 8 * ts);
+            hipLaunchKernelGGL(k_bitshuffle_generic, dim3(grid_for(items, 256, 256 * 16)), dim3(256), 0, s,
+                               dst, src, (uint64_t)n, ng, (uint32_t)ts, inv ? 1 : 0, (uint64_t)0);
+        }
+    }
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}

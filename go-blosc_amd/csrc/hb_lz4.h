@@ -1,0 +1,85 @@
+// hb_lz4.h — internal interface of the device LZ4 block codec (hb_lz4_enc.hip / hb_lz4_dec.hip).
+#pragma once
+#include "hb_common.h"
+
+// One wavefront encodes / decodes one chunk of the (filtered) buffer.
+#define HB_CHUNK        4096u            // bytes of input per chunk; matches never leave their chunk
+#define HB_RSTRIDE      (HB_CHUNK + 64u) // bytes reserved per chunk record in the workspace
+#define HB_TILE_CHUNKS  256u             // chunks per scan tile (one workgroup of the stitch kernel)
+
+// Restart index ("HBIX"), written AFTER cbytes of a frame (the reference decoder never looks there,
+// blosc.go:385-393) or into a caller buffer for a bare block.
+//   header  : 8 x u32 { magic, version|entry_size<<16, nunits, chunk_bytes, payload_bytes, nbytes, 0, check }
+//   entries : (nunits + 1) x { u32 src_off, dst_off, lit_rem, tok_off }
+// Entry k says: when the serial decoder has produced dst_off bytes it is at payload offset src_off, inside a
+// literal run with lit_rem bytes still to copy, whose token sits at tok_off.  lit_rem == HB_IDX_AT_TOKEN
+// means "src_off is a token".  The last entry is the terminator { payload_bytes, nbytes, 0, 0 }.
+#define HB_IDX_MAGIC     0x58494248u     // "HBIX"
+#define HB_IDX_VERSION   1u
+#define HB_IDX_HDR_BYTES 32u
+#define HB_IDX_ENTRY     16u
+#define HB_IDX_AT_TOKEN  0xFFFFFFFFu
+
+struct hb_enc_args {
+    const uint8_t *src; size_t n;        // bytes to encode (already filtered)
+    uint8_t *dst; size_t cap;            // frame != 0: frame start (payload at +16); else the block itself
+    uint8_t *index;                      // frame == 0: optional external index buffer
+    uint8_t *work; hb_result *result;
+    int frame, codec, shuffle, typesize;
+    unsigned opts;
+    const uint8_t *memcpy_src;           // what a memcpy frame stores (filtered bytes, or raw with HB_OPT_REFERENCE_MEMCPY)
+};
+
+struct hb_dec_args {
+    const uint8_t *src; size_t n;        // LZ4 block (frame payload)
+    uint8_t *dst; size_t cap;
+    const uint8_t *index; size_t index_bytes;
+    uint8_t *work; hb_result *result;
+    int frame; uint32_t expect;          // frame != 0: decoded length must equal expect (blosc.go:429-431)
+    int memcpy_payload;                  // blosc.go:398-400
+};
+
+size_t hb_lz4_enc_workspace(size_t n);
+size_t hb_lz4_dec_workspace(size_t n_out);
+size_t hb_lz4_index_bound(size_t n);
+int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s);
+int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s);
+
+// ---- small device helpers shared by encoder and decoder ----
+__device__ __forceinline__ uint32_t lz4_ext_bytes(uint32_t x) { return x < 15u ? 0u : 1u + (x - 15u) / 255u; }
+
+// wave-cooperative byte copy, any alignment, global -> global; dst-aligned 16-byte stores in the body
+__device__ __forceinline__ void wave_copy_g2g(uint8_t *dst, const uint8_t *src, uint32_t len, int lane) {
+    if (len == 0) return;
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > len) head = len;
+    if ((uint32_t)lane < head) dst[lane] = src[lane];
+    const uint32_t body = (len - head) >> 4;
+    for (uint32_t i = lane; i < body; i += 64) st16u(dst + head + i * 16u, ld16u(src + head + i * 16u));
+    const uint32_t done = head + body * 16u;
+    if (done + lane < len) dst[done + lane] = src[done + lane];
+}
+
+// wave-cooperative fill
+__device__ __forceinline__ void wave_fill_g(uint8_t *dst, uint8_t val, uint32_t len, int lane) {
+    if (len == 0) return;
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > len) head = len;
+    if ((uint32_t)lane < head) dst[lane] = val;
+    const uint32_t body = (len - head) >> 4;
+    const uint32_t w = val * 0x01010101u;
+    u32x4 v; v.x = w; v.y = w; v.z = w; v.w = w;
+    for (uint32_t i = lane; i < body; i += 64) st16u(dst + head + i * 16u, v);
+    const uint32_t done = head + body * 16u;
+    if (done + lane < len) dst[done + lane] = val;
+}
+
+// token + length-extension bytes of one LZ4 sequence header: [token][255 ...][rest]
+__device__ __forceinline__ void wave_write_lit_header(uint8_t *dst, uint32_t lit, uint32_t mcode, int lane) {
+    const uint32_t nb = lz4_ext_bytes(lit);
+    if (lane == 0) dst[0] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | mcode);
+    if (nb) {
+        wave_fill_g(dst + 1, 0xFF, nb - 1, lane);
+        if (lane == 0) dst[nb] = (uint8_t)((lit - 15u) - 255u * (nb - 1));
+    }
+}

@@ -1,0 +1,306 @@
+// hb_lz4_dec.hip — LZ4 block decoder for gfx950: replaces lz4Codec.Decompress (codec.go:77-84, i.e.
+// lz4.UncompressBlock of pierrec/lz4 v4.1.23) on the device.
+//
+// An LZ4 block is a serial chain, so there are two decoders:
+//
+//   k_dec_indexed : for blocks that come with a restart index (HBIX, see hb_lz4.h) — every block this
+//       library encodes.  One wavefront per index unit (= one 4 KiB chunk of output): the unit's slice of
+//       the stream is staged in LDS, parsed token by token (wave-uniform), literals and matches are copied
+//       cooperatively into an LDS image of the chunk (overlapping matches via i mod offset, no serial
+//       dependence), and the image is flushed with coalesced 16-byte stores.  The index is NOT trusted:
+//       each unit checks that it ends exactly in the state the next entry claims (stream offset, output
+//       offset, literals left in the current run, token position) and that no match reaches before its
+//       own output.  By induction over the units the result is then byte-identical to a serial decode.
+//       Any violation only raises a flag ...
+//   k_dec_serial  : ... in which case (or when there is no index: streams produced by the reference) a
+//       single wavefront decodes the whole block front to back through HBM.  Correct for every input the
+//       reference decoder accepts, rejects what it rejects (offset 0, offset before the start of the
+//       block, truncated input, output overflow); slow.
+//
+// Algorithmic HBM bytes: C (read) + n (write).
+#include "hb_lz4.h"
+
+struct DecPlan {
+    uint32_t mode;        // 0 = serial, 1 = indexed
+    uint32_t fail;        // set by any indexed unit that cannot vouch for its slice
+    uint32_t nunits;
+    uint32_t nbytes;      // decoded size the index declares
+};
+enum { DEC_SERIAL = 0, DEC_INDEXED = 1 };
+
+size_t hb_lz4_dec_workspace(size_t) { return 256; }
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return ld4u(p); }
+
+// 1 thread: is there a usable index?
+__global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_bytes, uint64_t n_src, uint64_t cap,
+                           DecPlan *plan, hb_result *result) {
+    plan->mode = DEC_SERIAL; plan->fail = 0; plan->nunits = 0; plan->nbytes = 0;
+    result->status = HB_OK; result->flags = 0; result->bytes = 0; result->total_bytes = 0; result->reserved = 0;
+    if (!index || index_bytes < HB_IDX_HDR_BYTES + 2 * HB_IDX_ENTRY) return;
+    uint32_t h[8];
+    for (int i = 0; i < 8; i++) h[i] = ld32(index + 4 * i);
+    if (h[0] != HB_IDX_MAGIC || h[1] != (HB_IDX_VERSION | (HB_IDX_ENTRY << 16))) return;
+    if (h[7] != (h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5])) return;
+    const uint64_t nunits = h[2];
+    if (nunits == 0 || HB_IDX_HDR_BYTES + (nunits + 1) * HB_IDX_ENTRY > index_bytes) return;
+    if (h[4] != n_src || h[5] > cap) return;
+    plan->nunits = (uint32_t)nunits;
+    plan->nbytes = h[5];
+    plan->mode = DEC_INDEXED;
+}
+
+#define DEC_IN_MAX  (HB_CHUNK + 256u)    // largest stream slice a unit may have
+#define DEC_OUT_MAX HB_CHUNK             // largest output a unit may have
+
+__global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
+                                                    uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
+                                                    DecPlan *plan) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_MAX + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
+    if (plan->mode != DEC_INDEXED) return;
+    const int lane = threadIdx.x;
+    const uint32_t nunits = plan->nunits;
+    const uint8_t *ent = index + HB_IDX_HDR_BYTES;
+    const uint32_t nbytes = ld32(index + 20);
+
+    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const uint32_t s0 = ld32(ent + 16 * (size_t)u), d0 = ld32(ent + 16 * (size_t)u + 4);
+        uint32_t rem = ld32(ent + 16 * (size_t)u + 8);
+        uint32_t tokpos = ld32(ent + 16 * (size_t)u + 12);
+        const uint32_t s1 = ld32(ent + 16 * (size_t)(u + 1)), d1 = ld32(ent + 16 * (size_t)(u + 1) + 4);
+        const uint32_t rem1 = ld32(ent + 16 * (size_t)(u + 1) + 8), tok1 = ld32(ent + 16 * (size_t)(u + 1) + 12);
+        const bool last = (u + 1 == nunits);
+        bool ok = s0 <= s1 && s1 <= n_src && d0 <= d1 && d1 <= nbytes && (s1 - s0) <= DEC_IN_MAX && (d1 - d0) <= DEC_OUT_MAX;
+        if (u == 0) ok = ok && s0 == 0 && d0 == 0 && rem == HB_IDX_AT_TOKEN;
+        if (last) ok = ok && s1 == n_src && d1 == nbytes;
+        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
+        const uint32_t slen = s1 - s0, outlen = d1 - d0;
+        // stage the slice
+        const uint8_t *g = src + s0;
+        const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
+        {
+            const u32x4 *ga = (const u32x4 *)(g - sh);
+            const uint32_t nv = (sh + slen + 15u) >> 4;
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_in)[i] = ga[i];
+        }
+        uint32_t tok = 0;
+        if (rem != HB_IDX_AT_TOKEN) { if (tokpos >= n_src) ok = false; else tok = src[tokpos]; }
+        wave_sync();
+        const uint8_t *in = s_in + sh;
+        uint32_t si = 0, di = 0;
+        bool at_token = false;       // state when the unit stops
+        if (rem == HB_IDX_AT_TOKEN) { rem = 0; goto parse_token; }
+        for (;;) {
+            {   // literal phase
+                const uint32_t take = min(rem, outlen - di);
+                if (take > slen - si) { ok = false; break; }
+                for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = in[si + i];
+                si += take; di += take; rem -= take;
+            }
+            if (rem > 0 || di == outlen) { at_token = false; break; }
+            {   // match phase
+                if (si == slen) { ok = false; break; }            // block ends after literals: short output -> serial decides
+                if (slen - si < 2) { ok = false; break; }
+                const uint32_t offset = (uint32_t)in[si] | ((uint32_t)in[si + 1] << 8);
+                si += 2;
+                uint32_t mlen = (tok & 15u) + 4u;
+                if ((tok & 15u) == 15u) {
+                    for (;;) {
+                        if (si >= slen) { ok = false; break; }
+                        const uint32_t b = in[si++];
+                        mlen += b;
+                        if (b != 255u) break;
+                        if (mlen > DEC_OUT_MAX + 4u) { ok = false; break; }
+                    }
+                    if (!ok) break;
+                }
+                if (offset == 0 || offset > di || mlen > outlen - di) { ok = false; break; }
+                wave_sync();                                       // earlier s_out writes visible
+                if (offset >= 64u) {
+                    for (uint32_t b0 = 0; b0 < mlen; b0 += 64) {
+                        const uint32_t i = b0 + lane;
+                        uint8_t v = 0;
+                        if (i < mlen) v = s_out[di + i - offset];
+                        if (i < mlen) s_out[di + i] = v;
+                        wave_sync();
+                    }
+                } else {
+                    uint32_t m = (uint32_t)lane % offset;          // source is always inside [di-offset, di)
+                    const uint32_t step = 64u % offset;
+                    for (uint32_t b0 = 0; b0 < mlen; b0 += 64) {
+                        const uint32_t i = b0 + lane;
+                        if (i < mlen) s_out[di + i] = s_out[di - offset + m];
+                        m += step; if (m >= offset) m -= offset;
+                    }
+                }
+                di += mlen;
+            }
+            if (si == slen || di == outlen) { at_token = true; break; }
+        parse_token:
+            tokpos = s0 + si;
+            tok = in[si++];
+            rem = tok >> 4;
+            if (rem == 15u) {
+                for (;;) {
+                    if (si >= slen) { ok = false; break; }
+                    const uint32_t b = in[si++];
+                    rem += b;
+                    if (b != 255u) break;
+                }
+                if (!ok) break;
+            }
+        }
+        // end-state check against the next entry
+        if (ok) {
+            ok = (si == slen) && (di == outlen);
+            if (last) ok = ok && (at_token || rem == 0);
+            else if (at_token) ok = ok && rem1 == HB_IDX_AT_TOKEN;
+            else ok = ok && rem1 == rem && tok1 == tokpos;
+        }
+        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); wave_sync(); continue; }
+        wave_sync();
+        // flush the chunk image
+        {
+            uint8_t *o = dst + d0;
+            uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);
+            if (head > outlen) head = outlen;
+            if ((uint32_t)lane < head) o[lane] = s_out[lane];
+            const uint32_t body = (outlen - head) >> 4;
+            if (head == 0) { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + i * 16u) = *(const u32x4 *)(s_out + i * 16u); }
+            else {
+                for (uint32_t i = lane; i < body; i += 64) {
+                    const uint8_t *p = s_out + head + i * 16u;
+                    u32x4 v;
+                    v.x = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                    v.y = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
+                    v.z = (uint32_t)p[8] | ((uint32_t)p[9] << 8) | ((uint32_t)p[10] << 16) | ((uint32_t)p[11] << 24);
+                    v.w = (uint32_t)p[12] | ((uint32_t)p[13] << 8) | ((uint32_t)p[14] << 16) | ((uint32_t)p[15] << 24);
+                    *(u32x4 *)(o + head + i * 16u) = v;
+                }
+            }
+            const uint32_t done = head + body * 16u;
+            if (done + lane < outlen) o[done + lane] = s_out[done + lane];
+        }
+        wave_sync();
+    }
+}
+
+// agent-scope relaxed byte load: served by L2, never by this CU's L1 (the wave re-reads bytes it stored)
+__device__ __forceinline__ uint8_t ld_l2(const uint8_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wavefront, whole block, front to back.  Semantics of lz4.UncompressBlock (see oracle/blosc_oracle.c
+// ob_lz4_decompress for the restated rules).
+__global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ src, uint64_t n_src,
+                                                   uint8_t *__restrict__ dst, uint64_t cap, DecPlan *plan,
+                                                   hb_result *result, int frame, uint32_t expect) {
+    const int lane = threadIdx.x;
+    if (plan->mode == DEC_INDEXED && !plan->fail) {
+        if (lane == 0) {
+            const uint64_t got = plan->nbytes;
+            result->flags = 1; result->bytes = got; result->total_bytes = got;
+            result->status = (frame && got != expect) ? HB_ERR_SIZE_MISMATCH : HB_OK;     // blosc.go:429-431
+        }
+        return;
+    }
+    uint64_t si = 0, di = 0;
+    int err = 0;
+    while (si < n_src) {
+        const uint32_t b = src[si++];
+        uint64_t ll = b >> 4;
+        if (ll == 15) {
+            for (;;) {
+                if (si >= n_src) { err = 1; break; }
+                const uint32_t x = src[si++];
+                ll += x;
+                if (x != 255u) break;
+            }
+            if (err) break;
+        }
+        if (ll) {
+            if (ll > n_src - si || ll > cap - di) { err = 1; break; }
+            for (uint64_t off = 0; off < ll; off += 1u << 30) {
+                const uint32_t part = (uint32_t)min((uint64_t)1u << 30, ll - off);
+                wave_copy_g2g(dst + di + off, src + si + off, part, lane);
+            }
+            si += ll; di += ll;
+        }
+        uint64_t ml = b & 15u;
+        if (si == n_src && ml == 0) break;
+        if (si >= n_src || n_src - si < 2) { err = 1; break; }
+        const uint32_t offset = (uint32_t)src[si] | ((uint32_t)src[si + 1] << 8);
+        if (offset == 0) { err = 1; break; }
+        si += 2;
+        ml += 4;
+        if (ml == 19) {
+            for (;;) {
+                if (si >= n_src) { err = 1; break; }
+                const uint32_t x = src[si++];
+                ml += x;
+                if (x != 255u) break;
+            }
+            if (err) break;
+        }
+        if (di < offset || ml > cap - di) { err = 1; break; }
+        // the source bytes were stored by this wave: wait for the stores, then read them from L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint8_t *m = dst + di - offset;
+        if (offset >= 64u) {
+            for (uint64_t b0 = 0; b0 < ml; b0 += 64) {
+                const uint64_t i = b0 + lane;
+                uint8_t v = 0;
+                if (i < ml) v = ld_l2(m + i);
+                if (i < ml) dst[di + i] = v;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            uint32_t mm = (uint32_t)lane % offset;
+            const uint32_t step = 64u % offset;
+            uint8_t pat = ld_l2(m + mm);
+            for (uint64_t b0 = 0; b0 < ml; b0 += 64) {
+                const uint64_t i = b0 + lane;
+                if (step) pat = ld_l2(m + mm);
+                if (i < ml) dst[di + i] = pat;
+                mm += step; if (mm >= offset) mm -= offset;
+            }
+        }
+        di += ml;
+    }
+    if (lane == 0) {
+        result->flags = 0;
+        if (err) { result->status = HB_ERR_DECOMPRESSION_FAILED; result->bytes = 0; }            // blosc.go:411-413
+        else if (frame && di != expect) { result->status = HB_ERR_SIZE_MISMATCH; result->bytes = di; }   // blosc.go:429-431
+        else { result->status = HB_OK; result->bytes = di; }
+    }
+}
+
+__global__ void k_set_result(hb_result *result, int status, uint64_t bytes) {
+    result->status = status; result->flags = 0; result->bytes = bytes; result->total_bytes = bytes; result->reserved = 0;
+}
+
+int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
+    if (a.memcpy_payload) {                                           // blosc.go:398-400
+        if (a.n != a.expect) {                                        // -> blosc.go:429-431
+            hipLaunchKernelGGL(k_set_result, dim3(1), dim3(1), 0, s, a.result, HB_ERR_SIZE_MISMATCH, (uint64_t)a.n);
+        } else {
+            if (a.n) HB_HIP_TRY(hipMemcpyAsync(a.dst, a.src, a.n, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(k_set_result, dim3(1), dim3(1), 0, s, a.result, HB_OK, (uint64_t)a.n);
+        }
+        HB_HIP_TRY(hipGetLastError());
+        return HB_OK;
+    }
+    DecPlan *plan = (DecPlan *)a.work;
+    hipLaunchKernelGGL(k_dec_plan, dim3(1), dim3(1), 0, s, a.index, (uint64_t)a.index_bytes, (uint64_t)a.n,
+                       (uint64_t)a.cap, plan, a.result);
+    if (a.index) {
+        const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
+        const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u ? units : 256u * 64u));
+        hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan);
+    }
+    hipLaunchKernelGGL(k_dec_serial, dim3(1), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (uint64_t)a.cap, plan,
+                       a.result, a.frame, a.expect);
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}

@@ -1,0 +1,443 @@
+// hb_lz4_enc.hip — LZ4 block encoder for gfx950: replaces lz4Codec.Compress (codec.go:63-75, i.e.
+// lz4.CompressBlock of pierrec/lz4 v4.1.23) on the device.
+//
+// The reference decodes a frame payload with ONE UncompressBlock call (codec.go:79), so the output has to
+// be one spec-valid LZ4 block.  A block is a serial chain of sequences; it is built in parallel like this:
+//
+//   k_match  : one wavefront per 4 KiB chunk.  The chunk sits in LDS; every step the 64 lanes hash the 4
+//              bytes at 64 consecutive positions, probe/insert a 2048-entry u16 table in LDS, verify the
+//              candidates, and the wave then walks the hits in order (ballot + readlane), extending each
+//              match cooperatively (64 byte compares per step).  Matches never leave the chunk, the last 5
+//              bytes of a chunk stay literals and no match starts in its last 12 (LZ4 end-of-block rules,
+//              applied per chunk so that the very last chunk satisfies them).  The wave emits its sequences
+//              into an LDS buffer and flushes them as one coalesced record:
+//                  [lead literals][rest of sequence 0][sequence 1]...[sequence m-1][trailing literals]
+//              Sequence 0 has no token yet: its literal run also contains whatever the previous chunks
+//              left un-matched, which only the scan knows.
+//   k_tiles, k_scan : an associative scan over chunk summaries (has-match, first match position F, bytes,
+//              last match end E) gives every chunk the stream offset of its segment and the length of the
+//              literal run that closes it; a suffix scan gives the position of the NEXT match (the header
+//              of a literal run depends on its total length, which is only known at its end).
+//   k_stitch : every chunk writes exactly the bytes it owns in the final block: its segment header
+//              (token + 255-extension), its encoded bytes, and its trailing literals at their place inside
+//              the literal run that a later chunk (or the end of the block) closes.  Also writes the frame
+//              header / memcpy fallback (blosc.go:342-371) and the restart index.
+//
+// Algorithmic HBM bytes: n (read) + C (write).  The records cost another ~n written + ~n read; see DESIGN.md.
+#include "hb_lz4.h"
+
+#define HLOG 11
+#define HSIZE (1u << HLOG)
+
+struct __attribute__((aligned(16))) ChunkDesc {
+    uint32_t lead;      // literals before the first match (chunk-relative)
+    uint32_t enc_len;   // record bytes before the trailing literals (lead + encoded sequences)
+    uint32_t last_end;  // chunk-relative end of the last match; 0 = chunk has no match
+    uint32_t mcode0;    // match-length nibble of sequence 0
+};
+
+// summary of a run of chunks; combine() is associative (not commutative)
+struct Agg {
+    int64_t fixed;      // stream bytes of all segments in the run, minus [ext(F - a) - a] of the first one
+    uint32_t F;         // position of the first match in the run
+    uint32_t E;         // end of the last match in the run
+    uint32_t has;       // run contains a match
+    uint32_t pad;
+};
+
+__device__ __forceinline__ Agg agg_identity() { Agg r; r.fixed = 0; r.F = 0; r.E = 0; r.has = 0; r.pad = 0; return r; }
+__device__ __forceinline__ Agg agg_combine(const Agg &x, const Agg &y) {
+    if (!y.has) return x;
+    if (!x.has) return y;
+    Agg r;
+    r.has = 1; r.pad = 0; r.F = x.F; r.E = y.E;
+    r.fixed = x.fixed + y.fixed + (int64_t)lz4_ext_bytes(y.F - x.E) - (int64_t)x.E;
+    return r;
+}
+__device__ __forceinline__ Agg agg_of_chunk(const ChunkDesc &d, uint32_t start) {
+    Agg r = agg_identity();
+    if (d.last_end) {
+        r.has = 1; r.F = start + d.lead; r.E = start + d.last_end;
+        r.fixed = 1 + (int64_t)start + (int64_t)d.enc_len;     // segment = 1 + ext(F-a) + (start-a) + enc_len
+    }
+    return r;
+}
+// stream bytes of a whole prefix summarised by p, the stream starting at position 0
+__device__ __forceinline__ int64_t agg_bytes(const Agg &p) { return p.has ? p.fixed + (int64_t)lz4_ext_bytes(p.F) : 0; }
+
+struct EncPlan {
+    uint64_t cbytes_block;   // LZ4 block bytes
+    uint32_t use_memcpy;
+    uint32_t nchunks;
+    uint64_t index_off;      // byte offset of the index from dst (frame) or 0 (external buffer)
+    uint64_t pad[4];
+};
+
+// workspace layout
+struct EncLayout {
+    size_t plan, desc, tile_agg, tile_nf, tile_pre, tile_suf, records, total;
+    uint32_t nchunks, ntiles;
+};
+static inline EncLayout enc_layout(size_t n) {
+    EncLayout L;
+    L.nchunks = (uint32_t)((n + HB_CHUNK - 1) / HB_CHUNK);
+    L.ntiles = (L.nchunks + HB_TILE_CHUNKS - 1) / HB_TILE_CHUNKS;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    L.plan = take(sizeof(EncPlan));
+    L.desc = take((size_t)L.nchunks * sizeof(ChunkDesc));
+    L.tile_agg = take((size_t)L.ntiles * sizeof(Agg));
+    L.tile_nf = take((size_t)L.ntiles * 4);
+    L.tile_pre = take((size_t)L.ntiles * sizeof(Agg));
+    L.tile_suf = take((size_t)L.ntiles * 4);
+    L.records = take((size_t)L.nchunks * HB_RSTRIDE + 256);
+    L.total = o;
+    return L;
+}
+size_t hb_lz4_enc_workspace(size_t n) { return enc_layout(n).total; }
+size_t hb_lz4_index_bound(size_t n) {
+    return HB_IDX_HDR_BYTES + (size_t)HB_IDX_ENTRY * ((n + HB_CHUNK - 1) / HB_CHUNK + 1);
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_match
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_read4(const uint8_t *base, uint32_t a) {
+    const uint32_t *w = (const uint32_t *)base;
+    const uint32_t w0 = w[a >> 2], w1 = w[(a >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+}
+
+__global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
+                                              ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
+                                              uint32_t nchunks) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
+    const int lane = threadIdx.x;
+
+    for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
+        const uint64_t start = (uint64_t)ck * HB_CHUNK;
+        const int len = (int)((n - start) < HB_CHUNK ? (n - start) : HB_CHUNK);
+        const uint8_t *g = src + start;
+        const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
+        // stage the chunk: 16-byte aligned vectors (over-reads stay inside the first/last 16-byte block)
+        {
+            const u32x4 *ga = (const u32x4 *)(g - sh);
+            const uint32_t nv = (sh + (uint32_t)len + 15u) >> 4;
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_data)[i] = ga[i];
+            u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
+            for (uint32_t i = lane; i < HSIZE * 2 / 16; i += 64) ((u32x4 *)s_tab)[i] = z;
+        }
+        wave_sync();
+
+        int pos = 0, anchor = 0, o = 0, nseq = 0;
+        uint32_t lead = 0, mcode0 = 0;
+        const int mstart_max = len - 12;     // last position a match may start at
+        const int mend_max = len - 5;        // matches end at or before this
+        while (pos <= mstart_max) {
+            const int p = pos + lane;
+            const uint32_t v = lds_read4(s_data, sh + (uint32_t)p);
+            const bool valid = p <= mstart_max;
+            const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
+            const uint32_t cand = s_tab[h];
+            wave_sync();
+            if (valid) s_tab[h] = (uint16_t)p;
+            const uint32_t cv = lds_read4(s_data, sh + cand);
+            const bool ism = valid && (int)cand < p && cv == v;
+            unsigned long long mask = __ballot(ism);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                const int mp = pos + l;
+                const int mc = (int)__builtin_amdgcn_readlane(cand, l);
+                // cooperative forward extension
+                int mlen = 4;
+                const int maxl = mend_max - mp;
+                for (;;) {
+                    const int i = mlen + lane;
+                    const bool ne = (i >= maxl) || s_data[sh + mp + i] != s_data[sh + mc + i];
+                    const unsigned long long m2 = __ballot(ne);
+                    if (m2) { mlen += __builtin_ctzll(m2); break; }
+                    mlen += 64;
+                }
+                // emit [token][litlen ext][literals][offset][matchlen ext]; sequence 0 has no token yet
+                const int lit = mp - anchor;
+                const uint32_t mcode = (uint32_t)(mlen - 4);
+                if (nseq == 0) { lead = (uint32_t)lit; mcode0 = mcode < 15u ? mcode : 15u; }
+                else {
+                    const uint32_t nb = lz4_ext_bytes((uint32_t)lit);
+                    if (lane == 0) s_out[o] = (uint8_t)((((uint32_t)lit < 15u ? (uint32_t)lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+                    if ((uint32_t)lane < nb)
+                        s_out[o + 1 + lane] = ((uint32_t)lane + 1 < nb) ? 255 : (uint8_t)(((uint32_t)lit - 15u) - 255u * (nb - 1));
+                    o += 1 + (int)nb;
+                }
+                for (int i = lane; i < lit; i += 64) s_out[o + i] = s_data[sh + anchor + i];
+                o += lit;
+                const uint32_t off = (uint32_t)(mp - mc);
+                if (lane < 2) s_out[o + lane] = (uint8_t)(off >> (8 * lane));
+                o += 2;
+                {
+                    const uint32_t nb = lz4_ext_bytes(mcode);
+                    if ((uint32_t)lane < nb)
+                        s_out[o + lane] = ((uint32_t)lane + 1 < nb) ? 255 : (uint8_t)((mcode - 15u) - 255u * (nb - 1));
+                    o += (int)nb;
+                }
+                nseq++;
+                anchor = mp + mlen;
+                const int rel = anchor - pos;
+                mask = rel >= 64 ? 0ull : (mask & (~0ull << rel));
+            }
+            pos = anchor > pos + 64 ? anchor : pos + 64;
+        }
+        // trailing literals, raw
+        const int trail = len - anchor;
+        for (int i = lane; i < trail; i += 64) s_out[o + i] = s_data[sh + anchor + i];
+        wave_sync();
+        const int total = o + trail;
+        uint8_t *rec = records + (size_t)ck * HB_RSTRIDE;
+        for (int i = lane * 16; i < total; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_out + i);
+        if (lane == 0) {
+            ChunkDesc d;
+            d.lead = nseq ? lead : 0u; d.enc_len = nseq ? (uint32_t)o : 0u;
+            d.last_end = nseq ? (uint32_t)anchor : 0u; d.mcode0 = mcode0;
+            desc[ck] = d;
+        }
+        wave_sync();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// scans
+// ----------------------------------------------------------------------------------------------
+// inclusive scan of 256 Aggs in LDS (Hillis-Steele, ordered)
+__device__ __forceinline__ void block_scan_agg(Agg *s, int t) {
+    for (int d = 1; d < 256; d <<= 1) {
+        Agg x = s[t];
+        Agg y = (t >= d) ? s[t - d] : agg_identity();
+        __syncthreads();
+        s[t] = agg_combine(y, x);
+        __syncthreads();
+    }
+}
+
+// per tile: aggregate of its chunks + position of its first match
+__global__ __launch_bounds__(256) void k_tiles(const ChunkDesc *__restrict__ desc, uint32_t nchunks,
+                                               Agg *__restrict__ tile_agg, uint32_t *__restrict__ tile_nf) {
+    __shared__ Agg s[256];
+    __shared__ uint32_t s_nf[256];
+    const int t = threadIdx.x;
+    const uint32_t ck = blockIdx.x * HB_TILE_CHUNKS + t;
+    Agg a = agg_identity();
+    if (ck < nchunks) a = agg_of_chunk(desc[ck], ck * HB_CHUNK);
+    s[t] = a;
+    s_nf[t] = a.has ? a.F : 0xFFFFFFFFu;
+    __syncthreads();
+    block_scan_agg(s, t);
+    for (int d = 128; d > 0; d >>= 1) {
+        if (t < d) s_nf[t] = min(s_nf[t], s_nf[t + d]);
+        __syncthreads();
+    }
+    if (t == 0) { tile_agg[blockIdx.x] = s[255]; tile_nf[blockIdx.x] = s_nf[0]; }
+}
+
+struct FrameInfo { int frame, codec, shuffle, typesize; unsigned opts; };
+
+// one workgroup: exclusive prefix of tile aggregates, exclusive suffix-min of tile first-match positions,
+// total size, memcpy decision, frame header, result record.
+__global__ __launch_bounds__(256) void k_scan(const Agg *__restrict__ tile_agg, const uint32_t *__restrict__ tile_nf,
+                                              Agg *__restrict__ tile_pre, uint32_t *__restrict__ tile_suf,
+                                              uint32_t ntiles, uint32_t nchunks, uint64_t n, EncPlan *plan,
+                                              uint8_t *dst, FrameInfo fi, hb_result *result, int has_index) {
+    __shared__ Agg s[256];
+    __shared__ uint32_t s_nf[256];
+    __shared__ Agg carry;
+    __shared__ uint32_t carry_nf;
+    const int t = threadIdx.x;
+    if (t == 0) { carry = agg_identity(); carry_nf = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 256) {       // forward
+        const uint32_t i = base + t;
+        s[t] = (i < ntiles) ? tile_agg[i] : agg_identity();
+        __syncthreads();
+        block_scan_agg(s, t);
+        const Agg excl = agg_combine(carry, t ? s[t - 1] : agg_identity());
+        if (i < ntiles) tile_pre[i] = excl;
+        __syncthreads();
+        if (t == 0) carry = agg_combine(carry, s[255]);
+        __syncthreads();
+    }
+    for (int64_t base = (int64_t)((ntiles + 255) / 256) * 256 - 256; base >= 0; base -= 256) {   // backward
+        const uint32_t i = (uint32_t)base + t;
+        s_nf[t] = (i < ntiles) ? tile_nf[i] : 0xFFFFFFFFu;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {      // inclusive suffix min
+            const uint32_t x = s_nf[t], y = (t + d < 256) ? s_nf[t + d] : 0xFFFFFFFFu;
+            __syncthreads();
+            s_nf[t] = min(x, y);
+            __syncthreads();
+        }
+        const uint32_t excl = min(carry_nf, (t + 1 < 256) ? s_nf[t + 1] : 0xFFFFFFFFu);
+        if (i < ntiles) tile_suf[i] = excl;
+        __syncthreads();
+        if (t == 0) carry_nf = min(carry_nf, s_nf[0]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        const Agg all = carry;
+        const uint64_t a2 = all.has ? all.E : 0;
+        const uint64_t tl = n - a2;                                   // final literal run
+        const uint64_t C = (uint64_t)agg_bytes(all) + 1 + lz4_ext_bytes((uint32_t)tl) + tl;
+        plan->cbytes_block = C;
+        plan->nchunks = nchunks;
+        uint32_t use_memcpy = 0;
+        uint64_t payload = C;
+        if (fi.frame) {
+            use_memcpy = C >= n;                                      // blosc.go:342
+            if (use_memcpy) payload = n;
+            uint8_t flags = 0;                                        // blosc.go:348-356
+            if (fi.shuffle == HB_SHUFFLE) flags |= HB_FLAG_SHUFFLE;
+            else if (fi.shuffle == HB_BITSHUFFLE) flags |= HB_FLAG_BITSHUFFLE;
+            if (use_memcpy) flags |= HB_FLAG_MEMCPY;
+            const uint32_t cbytes = (uint32_t)(HB_HEADER_SIZE + payload);
+            dst[0] = HB_FORMAT_VERSION; dst[1] = (uint8_t)fi.codec; dst[2] = flags; dst[3] = (uint8_t)fi.typesize;   // :358-366
+            ((uint32_t *)dst)[1] = (uint32_t)n; ((uint32_t *)dst)[2] = (uint32_t)n; ((uint32_t *)dst)[3] = cbytes;
+            result->flags = flags;
+            result->bytes = cbytes;
+            uint64_t total = cbytes;
+            plan->index_off = 0;
+            if (has_index && !use_memcpy) {
+                plan->index_off = ((uint64_t)cbytes + 7) & ~7ull;
+                total = plan->index_off + HB_IDX_HDR_BYTES + (uint64_t)HB_IDX_ENTRY * (nchunks + 1);
+            }
+            result->total_bytes = total;
+        } else {
+            if (nchunks == 0) dst[0] = 0;                             // empty input: a single zero token
+            result->flags = 0;
+            result->bytes = C;
+            result->total_bytes = C;
+            plan->index_off = 0;
+        }
+        plan->use_memcpy = use_memcpy;
+        result->status = HB_OK;
+        result->reserved = 0;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// k_stitch: one workgroup per tile of 256 chunks; wave w places chunks w, w+4, ...
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stitch(const ChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records,
+                                                const Agg *__restrict__ tile_pre, const uint32_t *__restrict__ tile_suf,
+                                                const EncPlan *__restrict__ plan, uint32_t nchunks, uint64_t n,
+                                                uint8_t *__restrict__ out /* block start */,
+                                                uint8_t *__restrict__ index_base_ext, uint8_t *__restrict__ frame_base,
+                                                const uint8_t *__restrict__ memcpy_src) {
+    __shared__ Agg s[256];
+    __shared__ uint32_t s_nf[256];
+    __shared__ ChunkDesc s_desc[256];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t ck0 = blockIdx.x * HB_TILE_CHUNKS;
+    const uint32_t cnt = min(HB_TILE_CHUNKS, nchunks - ck0);
+
+    if (plan->use_memcpy) {                                           // blosc.go:343-345: payload = (filtered) input
+        const uint64_t b0 = (uint64_t)ck0 * HB_CHUNK;
+        const uint64_t b1 = min((uint64_t)(ck0 + cnt) * HB_CHUNK, n);
+        for (uint64_t off = b0 + (uint64_t)wave * 65536u; off < b1; off += 4u * 65536u)
+            wave_copy_g2g(out + off, memcpy_src + off, (uint32_t)min((uint64_t)65536u, b1 - off), lane);
+        return;
+    }
+
+    ChunkDesc d; d.lead = 0; d.enc_len = 0; d.last_end = 0; d.mcode0 = 0;
+    if ((uint32_t)t < cnt) d = desc[ck0 + t];
+    s_desc[t] = d;
+    const Agg mine = ((uint32_t)t < cnt) ? agg_of_chunk(d, (ck0 + t) * HB_CHUNK) : agg_identity();
+    s[t] = mine;
+    s_nf[t] = mine.has ? mine.F : 0xFFFFFFFFu;
+    __syncthreads();
+    block_scan_agg(s, t);                                             // inclusive prefix within the tile
+    for (int dd = 1; dd < 256; dd <<= 1) {                            // inclusive suffix-min of F within the tile
+        const uint32_t x = s_nf[t], y = (t + dd < 256) ? s_nf[t + dd] : 0xFFFFFFFFu;
+        __syncthreads();
+        s_nf[t] = min(x, y);
+        __syncthreads();
+    }
+    const Agg tpre = tile_pre[blockIdx.x];
+    const uint32_t tsuf = tile_suf[blockIdx.x];
+    uint8_t *index = nullptr;
+    if (index_base_ext) index = index_base_ext;
+    else if (frame_base && plan->index_off) index = frame_base + plan->index_off;
+
+    for (uint32_t c = wave; c < cnt; c += 4) {
+        const uint32_t ck = ck0 + c;
+        const ChunkDesc cd = s_desc[c];
+        const uint32_t start = ck * HB_CHUNK;
+        const uint32_t end = (uint32_t)min((uint64_t)start + HB_CHUNK, n);
+        const Agg P = agg_combine(tpre, c ? s[c - 1] : agg_identity());          // everything before this chunk
+        uint32_t NF = min(tsuf, (c + 1 < 256) ? s_nf[c + 1] : 0xFFFFFFFFu);       // next match after this chunk
+        if (NF == 0xFFFFFFFFu) NF = (uint32_t)n;                                  // ... or the end of the block
+        const uint32_t a = P.has ? P.E : 0u;
+        const uint64_t O = (uint64_t)agg_bytes(P);
+        const uint8_t *rec = records + (size_t)ck * HB_RSTRIDE;
+        uint64_t I = O;
+        uint32_t a2 = a, tpos = start, roff = 0;
+        if (cd.last_end) {
+            const uint32_t tl = start + cd.lead - a;                  // literal run closed by this chunk's first match
+            const uint32_t hdr = 1 + lz4_ext_bytes(tl);
+            const uint32_t carry_lits = start - a;
+            wave_write_lit_header(out + O, tl, cd.mcode0, lane);
+            wave_copy_g2g(out + O + hdr + carry_lits, rec, cd.enc_len, lane);
+            I = O + hdr + carry_lits + cd.enc_len;
+            a2 = start + cd.last_end; tpos = a2; roff = cd.enc_len;
+        }
+        // trailing literals: part of the run that ends at NF
+        const uint32_t hdr2 = 1 + lz4_ext_bytes(NF - a2);
+        wave_copy_g2g(out + I + hdr2 + (tpos - a2), rec + roff, end - tpos, lane);
+        if (ck + 1 == nchunks) wave_write_lit_header(out + I, NF - a2, 0, lane);  // final literal-only sequence
+        if (index && lane == 0) {
+            uint32_t *e = (uint32_t *)(index + HB_IDX_HDR_BYTES) + 4 * (size_t)ck;
+            if (ck == 0) { e[0] = 0; e[1] = 0; e[2] = HB_IDX_AT_TOKEN; e[3] = 0; }
+            else {
+                const uint32_t Fc = cd.last_end ? start + cd.lead : NF;           // end of the run containing `start`
+                const uint32_t hdrc = 1 + lz4_ext_bytes(Fc - a);
+                e[0] = (uint32_t)(O + hdrc + (start - a)); e[1] = start; e[2] = Fc - start; e[3] = (uint32_t)O;
+            }
+            if (ck + 1 == nchunks) {
+                e[4] = (uint32_t)plan->cbytes_block; e[5] = (uint32_t)n; e[6] = 0; e[7] = 0;
+                uint32_t *h = (uint32_t *)index;
+                h[0] = HB_IDX_MAGIC; h[1] = HB_IDX_VERSION | (HB_IDX_ENTRY << 16); h[2] = nchunks; h[3] = HB_CHUNK;
+                h[4] = (uint32_t)plan->cbytes_block; h[5] = (uint32_t)n; h[6] = 0;
+                h[7] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// launch
+// ----------------------------------------------------------------------------------------------
+int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
+    const EncLayout L = enc_layout(a.n);
+    uint8_t *w = a.work;
+    EncPlan *plan = (EncPlan *)(w + L.plan);
+    ChunkDesc *desc = (ChunkDesc *)(w + L.desc);
+    Agg *tile_agg = (Agg *)(w + L.tile_agg), *tile_pre = (Agg *)(w + L.tile_pre);
+    uint32_t *tile_nf = (uint32_t *)(w + L.tile_nf), *tile_suf = (uint32_t *)(w + L.tile_suf);
+    uint8_t *records = w + L.records;
+    uint8_t *out = a.frame ? a.dst + HB_HEADER_SIZE : a.dst;
+    FrameInfo fi{a.frame, a.codec, a.shuffle, a.typesize, a.opts};
+    const int has_index = a.frame ? ((a.opts & HB_OPT_INDEX_TRAILER) ? 1 : 0) : (a.index ? 1 : 0);
+
+    if (L.nchunks) {
+        const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;
+        hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks);
+        hipLaunchKernelGGL(k_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg, tile_nf);
+    }
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, s, tile_agg, tile_nf, tile_pre, tile_suf, L.ntiles, L.nchunks,
+                       (uint64_t)a.n, plan, a.dst, fi, a.result, has_index);
+    if (L.nchunks)
+        hipLaunchKernelGGL(k_stitch, dim3(L.ntiles), dim3(256), 0, s, desc, records, tile_pre, tile_suf, plan, L.nchunks,
+                           (uint64_t)a.n, out, a.frame ? (uint8_t *)nullptr : a.index, a.frame ? a.dst : (uint8_t *)nullptr,
+                           a.memcpy_src);
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}

@@ -1,0 +1,349 @@
+"""Host-side mirror of go-blosc's public API over the hipblosc C ABI (include/hipblosc.h).
+
+Same names, argument meaning and error behaviour as the reference package (blosc.go / codec.go /
+shuffle.go), so the parity tests read like the reference's own tests.  Every O(n) operation runs on
+the MI355X through libhipblosc.so; there is no CPU fallback — importing works without the library
+(so `-m "not gpu"` tests can check symbols), calling anything without it / without a GPU raises.
+
+ctypes only: no torch types cross the boundary (device pointers are plain integers).
+"""
+import ctypes
+import os
+from dataclasses import dataclass
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhipblosc.so")
+
+# ---- constants, blosc.go:49-52, :57-64, :89-93, :110-121 ----
+Version = "1.0.0"
+FormatVersion = 2
+HeaderSize = MinHeaderSize = 16
+BloscLZ, LZ4, LZ4HC, Snappy, ZLIB, ZSTD = range(6)
+NoShuffle, Shuffle1, BitShuffle = 0, 1, 2
+flagShuffle, flagMemcpy, flagBitShuffle, flagSplit = 0x1, 0x2, 0x4, 0x8
+OP_SHUFFLE, OP_UNSHUFFLE, OP_BITSHUFFLE, OP_BITUNSHUFFLE = 0, 1, 2, 3
+OPT_INDEX_TRAILER, OPT_REFERENCE_MEMCPY = 0x1, 0x2
+
+_CODEC_NAMES = {BloscLZ: "blosclz", LZ4: "lz4", LZ4HC: "lz4hc", Snappy: "snappy", ZLIB: "zlib", ZSTD: "zstd"}
+_SHUFFLE_NAMES = {NoShuffle: "noshuffle", Shuffle1: "shuffle", BitShuffle: "bitshuffle"}
+
+
+def codec_string(c):      # Codec.String, blosc.go:67-84
+    return _CODEC_NAMES.get(c, f"unknown({c})")
+
+
+def shuffle_string(s):    # Shuffle.String, blosc.go:96-107
+    return _SHUFFLE_NAMES.get(s, f"unknown({s})")
+
+
+# ---- sentinel errors, blosc.go:125-149 ----
+class BloscError(Exception):
+    code = 0
+
+
+class ErrInvalidData(BloscError):
+    code = -1
+
+
+class ErrInvalidHeader(BloscError):
+    code = -2
+
+
+class ErrInvalidVersion(BloscError):
+    code = -3
+
+
+class ErrInvalidCodec(BloscError):
+    code = -4
+
+
+class ErrSizeMismatch(BloscError):
+    code = -5
+
+
+class ErrDataTooLarge(BloscError):
+    code = -6
+
+
+class ErrCompressionFailed(BloscError):
+    code = -7
+
+
+class ErrDecompressionFailed(BloscError):
+    code = -8
+
+
+class HipBloscError(BloscError):
+    """C-side failures that have no Go sentinel (no device, HIP error, bad argument, short buffer)."""
+
+
+_BY_CODE = {c.code: c for c in (ErrInvalidData, ErrInvalidHeader, ErrInvalidVersion, ErrInvalidCodec,
+                                ErrSizeMismatch, ErrDataTooLarge, ErrCompressionFailed, ErrDecompressionFailed)}
+
+EXPORTS = [
+    "hb_init", "hb_device_count", "hb_shutdown", "hb_strerror", "hb_version", "hb_host_alloc", "hb_host_free",
+    "hb_filter", "hb_filter_dev", "hb_lz4_bound", "hb_lz4_compress", "hb_lz4_decompress",
+    "hb_lz4_compress_workspace", "hb_lz4_decompress_workspace", "hb_lz4_compress_dev", "hb_lz4_decompress_dev",
+    "hb_index_bound", "hb_parse_header", "hb_header_bytes", "hb_frame_bound", "hb_compress_frame",
+    "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace",
+    "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi",
+]
+
+
+class hb_header(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_uint8), ("codec", ctypes.c_uint8), ("flags", ctypes.c_uint8),
+                ("typesize", ctypes.c_uint8), ("nbytes", ctypes.c_uint32), ("blocksize", ctypes.c_uint32),
+                ("cbytes", ctypes.c_uint32)]
+
+
+class hb_result(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("flags", ctypes.c_uint32), ("bytes", ctypes.c_uint64),
+                ("total_bytes", ctypes.c_uint64), ("reserved", ctypes.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C ABI.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipBloscError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, i32, i64, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int64, ctypes.c_uint
+        sig = {
+            "hb_init": (i32, []), "hb_device_count": (i32, []), "hb_shutdown": (None, []),
+            "hb_strerror": (ctypes.c_char_p, [i32]), "hb_version": (ctypes.c_char_p, []),
+            "hb_host_alloc": (vp, [sz]), "hb_host_free": (None, [vp]),
+            "hb_filter": (i32, [i32, vp, vp, sz, i32, i32]),
+            "hb_filter_dev": (i32, [i32, vp, vp, sz, i32, vp]),
+            "hb_lz4_bound": (sz, [sz]), "hb_index_bound": (sz, [sz]),
+            "hb_lz4_compress": (i64, [vp, sz, vp, sz, i32]),
+            "hb_lz4_decompress": (i64, [vp, sz, vp, sz, i32]),
+            "hb_lz4_compress_workspace": (sz, [sz]), "hb_lz4_decompress_workspace": (sz, [sz]),
+            "hb_lz4_compress_dev": (i32, [vp, sz, vp, sz, vp, sz, vp, sz, vp, vp]),
+            "hb_lz4_decompress_dev": (i32, [vp, sz, vp, sz, vp, sz, vp, sz, vp, vp]),
+            "hb_parse_header": (i32, [vp, sz, ctypes.POINTER(hb_header)]),
+            "hb_header_bytes": (None, [ctypes.POINTER(hb_header), vp]),
+            "hb_frame_bound": (sz, [sz]),
+            "hb_compress_frame": (i64, [vp, sz, vp, sz, i32, i32, i32, i32, u32, i32]),
+            "hb_decompress_frame": (i64, [vp, sz, vp, sz, i32, i32]),
+            "hb_compress_frame_workspace": (sz, [sz]), "hb_decompress_frame_workspace": (sz, [sz]),
+            "hb_compress_frame_dev": (i32, [vp, sz, vp, sz, i32, i32, i32, i32, u32, vp, sz, vp, vp]),
+            "hb_decompress_frame_dev": (i32, [vp, sz, vp, sz, i32, vp, sz, vp, vp]),
+            "hb_compress_frames_multi": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, u32]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _raise(code):
+    msg = lib().hb_strerror(int(code)).decode()
+    raise _BY_CODE.get(int(code), HipBloscError)(f"{msg} (code {code})")
+
+
+def _check(rc):
+    if rc < 0:
+        _raise(rc)
+    return rc
+
+
+def _buf(b):
+    """bytes-like -> (ctypes pointer, length, keepalive)"""
+    if isinstance(b, (bytes, bytearray)):
+        arr = (ctypes.c_char * len(b)).from_buffer_copy(b) if isinstance(b, bytes) else (ctypes.c_char * len(b)).from_buffer(b)
+        return ctypes.cast(arr, ctypes.c_void_p), len(b), arr
+    mv = memoryview(b).cast("B")
+    if mv.readonly:
+        arr = (ctypes.c_char * len(mv)).from_buffer_copy(mv)
+    else:
+        arr = (ctypes.c_char * len(mv)).from_buffer(mv)
+    return ctypes.cast(arr, ctypes.c_void_p), len(mv), arr
+
+
+# ---------------------------------------------------------------------------------------------
+# Header / Options, blosc.go:154-245
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Header:
+    Version: int = 0
+    VersionLZ: int = 0
+    Flags: int = 0
+    TypeSize: int = 0
+    NBytesOrig: int = 0
+    BlockSize: int = 0
+    NBytesComp: int = 0
+
+    def Bytes(self):                       # blosc.go:188-198
+        h = hb_header(self.Version, self.VersionLZ, self.Flags, self.TypeSize, self.NBytesOrig, self.BlockSize, self.NBytesComp)
+        out = ctypes.create_string_buffer(16)
+        lib().hb_header_bytes(ctypes.byref(h), ctypes.cast(out, ctypes.c_void_p))
+        return out.raw
+
+    def HasShuffle(self):                  # blosc.go:201-203
+        return self.Flags & flagShuffle != 0
+
+    def HasBitShuffle(self):               # blosc.go:206-208
+        return self.Flags & flagBitShuffle != 0
+
+    def IsMemcpy(self):                    # blosc.go:211-213
+        return self.Flags & flagMemcpy != 0
+
+    def ShuffleMode(self):                 # blosc.go:216-224 (bitshuffle wins)
+        if self.HasBitShuffle():
+            return BitShuffle
+        if self.HasShuffle():
+            return Shuffle1
+        return NoShuffle
+
+
+def ParseHeader(data):                     # blosc.go:165-185
+    p, n, keep = _buf(data)
+    h = hb_header()
+    _check(lib().hb_parse_header(p, n, ctypes.byref(h)))
+    return Header(h.version, h.codec, h.flags, h.typesize, h.nbytes, h.blocksize, h.cbytes)
+
+
+@dataclass
+class Options:                             # blosc.go:227-234
+    Codec: int = LZ4
+    Level: int = 0
+    Shuffle: int = NoShuffle
+    TypeSize: int = 0
+    BlockSize: int = 0                     # accepted and ignored, as in the reference (blosc.go:232)
+    NumThreads: int = 0                    # accepted and ignored (blosc.go:233)
+
+
+def DefaultOptions():                      # blosc.go:237-245
+    return Options(Codec=LZ4, Level=5, Shuffle=Shuffle1, TypeSize=4, BlockSize=0)
+
+
+# extra knobs that have no counterpart in the reference
+device = 0                                 # HIP device used by the host-pointer entry points
+default_opts = 0                           # OPT_* bits ORed into every Compress call
+
+
+def Compress(data, codec, level, shuffle, typeSize, opts=None):     # blosc.go:257-265
+    return CompressWithOptions(data, Options(Codec=codec, Level=level, Shuffle=shuffle, TypeSize=typeSize), opts)
+
+
+def CompressWithOptions(data, o, opts=None):                        # blosc.go:268-286 + compressBackend :320-374
+    p, n, keep = _buf(data)
+    if n == 0:
+        raise ErrInvalidData("blosc: invalid compressed data")      # bare sentinel, blosc.go:269-271
+    L = lib()
+    cap = L.hb_frame_bound(n)
+    out = ctypes.create_string_buffer(cap)
+    rc = L.hb_compress_frame(p, n, ctypes.cast(out, ctypes.c_void_p), cap, o.Codec, o.Level, o.Shuffle, o.TypeSize,
+                             default_opts if opts is None else opts, device)
+    _check(rc)
+    return out.raw[:rc]
+
+
+def Decompress(data):                                               # blosc.go:291-293
+    return DecompressWithSize(data, 0)
+
+
+def DecompressWithSize(data, typeSize):                             # blosc.go:296-303 + decompressBackend :377-434
+    p, n, keep = _buf(data)
+    if n < HeaderSize:
+        raise ErrInvalidHeader("blosc: invalid header")             # bare sentinel, blosc.go:297-299
+    h = ParseHeader(data)
+    L = lib()
+    out = ctypes.create_string_buffer(max(h.NBytesOrig, 1))
+    rc = L.hb_decompress_frame(p, n, ctypes.cast(out, ctypes.c_void_p), h.NBytesOrig, typeSize, device)
+    _check(rc)
+    return out.raw[:rc]
+
+
+def GetInfo(data):                                                  # blosc.go:306-308
+    return ParseHeader(data)
+
+
+def GetDecompressedSize(data):                                      # blosc.go:311-317
+    return ParseHeader(data).NBytesOrig
+
+
+# ---------------------------------------------------------------------------------------------
+# filters, shuffle.go
+# ---------------------------------------------------------------------------------------------
+def _filter(op, src, typeSize):
+    p, n, keep = _buf(src)
+    out = ctypes.create_string_buffer(max(n, 1))
+    _check(lib().hb_filter(op, ctypes.cast(out, ctypes.c_void_p), p, n, typeSize, device))
+    return out.raw[:n]
+
+
+def shuffleBytes(src, typeSize):           # shuffle.go:16-73
+    return _filter(OP_SHUFFLE, src, typeSize)
+
+
+def unshuffleBytes(src, typeSize):         # shuffle.go:76-133
+    return _filter(OP_UNSHUFFLE, src, typeSize)
+
+
+def bitShuffle(src, typeSize):             # shuffle.go:145-219
+    return _filter(OP_BITSHUFFLE, src, typeSize)
+
+
+def bitUnshuffle(src, typeSize):           # shuffle.go:222-295
+    return _filter(OP_BITUNSHUFFLE, src, typeSize)
+
+
+def ShuffleBuffer(data, typeSize, mode):   # shuffle.go:298-309: in place on a bytearray; unknown mode = no-op
+    if mode == Shuffle1:
+        data[:] = shuffleBytes(bytes(data), typeSize)
+    elif mode == BitShuffle:
+        data[:] = bitShuffle(bytes(data), typeSize)
+
+
+def UnshuffleBuffer(data, typeSize, mode):  # shuffle.go:312-323
+    if mode == Shuffle1:
+        data[:] = unshuffleBytes(bytes(data), typeSize)
+    elif mode == BitShuffle:
+        data[:] = bitUnshuffle(bytes(data), typeSize)
+
+
+# ---------------------------------------------------------------------------------------------
+# codec plugin seam, codec.go:15-53 — the device LZ4 codec is what RegisterCodec(LZ4, ...) installs
+# ---------------------------------------------------------------------------------------------
+class HipLZ4Codec:
+    """CodecInterface (codec.go:15-24) backed by hb_lz4_compress / hb_lz4_decompress."""
+
+    def Name(self):                        # codec.go:61
+        return "lz4"
+
+    def Compress(self, data, level):       # codec.go:63-75 (level ignored)
+        p, n, keep = _buf(data)
+        L = lib()
+        cap = L.hb_lz4_bound(n)
+        out = ctypes.create_string_buffer(cap)
+        rc = _check(L.hb_lz4_compress(p, n, ctypes.cast(out, ctypes.c_void_p), cap, device))
+        return out.raw[:rc]
+
+    def Decompress(self, data, expectedSize):   # codec.go:77-84: returns buf[:n], n may be < expectedSize
+        p, n, keep = _buf(data)
+        out = ctypes.create_string_buffer(max(expectedSize, 1))
+        rc = _check(lib().hb_lz4_decompress(p, n, ctypes.cast(out, ctypes.c_void_p), expectedSize, device))
+        return out.raw[:rc]
+
+
+codecs = {LZ4: HipLZ4Codec()}              # codec.go:27-33 (only the LZ4 codec lives on the device path)
+
+
+def RegisterCodec(id, codec):              # codec.go:36-38
+    codecs[id] = codec
+
+
+def GetCodec(id):                          # codec.go:41-44
+    c = codecs.get(id)
+    return c, c is not None
+
+
+def ListCodecs():                          # codec.go:47-53
+    return list(codecs.keys())

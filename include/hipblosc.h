@@ -1,0 +1,152 @@
+/*
+ * hipblosc.h — C ABI of the MI355X-native go-blosc hot path (Shuffle / BitShuffle filters,
+ * LZ4 block codec, frame layer).  This is the drop-in boundary: a cgo shim binds exactly
+ * these symbols in place of the reference's internal seams (INTEGRATION.md shows the Go
+ * side).  Plain pointers and sizes only; no torch, no HIP types in signatures (a stream
+ * is passed as an opaque `void*` = hipStream_t, NULL = the default stream).
+ *
+ * The reference has no FFI.  Each entry point names the reference interface it replaces
+ * (file:line into mrjoshuak/go-blosc).
+ *
+ * Conventions
+ *   - All functions are thread-safe and may be called from arbitrary OS threads.
+ *   - The library keeps no caller pointer after a call returns (cgo rule).
+ *   - int / int64_t returns: >= 0 success (byte counts where stated), < 0 an HB_ERR_* code.
+ *   - "host" entry points take host pointers and stage through the device; `_dev` entry
+ *     points take DEVICE pointers on the current HIP device, are asynchronous on `stream`,
+ *     and report through an hb_result record in device or pinned memory.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point
+ *     returns HB_ERR_NO_DEVICE.
+ */
+#ifndef HIPBLOSC_H
+#define HIPBLOSC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HB_VERSION_STRING "0.1.0"
+
+/* ---- error codes: one per Go sentinel (blosc.go:125-149) + C-side ones ---- */
+#define HB_OK                         0
+#define HB_ERR_INVALID_DATA         (-1)   /* ErrInvalidData         blosc.go:127; bare for empty input (:269) and bad cbytes (:385-390) */
+#define HB_ERR_INVALID_HEADER       (-2)   /* ErrInvalidHeader       blosc.go:130; bare for < 16 bytes (:166, :297) */
+#define HB_ERR_INVALID_VERSION      (-3)   /* ErrInvalidVersion      blosc.go:133; wrapped (:181) */
+#define HB_ERR_INVALID_CODEC        (-4)   /* ErrInvalidCodec        blosc.go:136; wrapped (:324, :406) */
+#define HB_ERR_SIZE_MISMATCH        (-5)   /* ErrSizeMismatch        blosc.go:139; wrapped (:430) */
+#define HB_ERR_DATA_TOO_LARGE       (-6)   /* ErrDataTooLarge        blosc.go:142 (declared, never returned by the reference; used here when sizes overflow uint32) */
+#define HB_ERR_COMPRESSION_FAILED   (-7)   /* ErrCompressionFailed   blosc.go:145; wrapped (:338) */
+#define HB_ERR_DECOMPRESSION_FAILED (-8)   /* ErrDecompressionFailed blosc.go:148; wrapped (:412) */
+#define HB_ERR_NO_DEVICE            (-9)   /* no HIP device / HIP runtime unusable */
+#define HB_ERR_HIP                  (-10)  /* a HIP runtime call failed */
+#define HB_ERR_BAD_ARG              (-11)  /* NULL pointer, overlapping buffers, bad op ... */
+#define HB_ERR_SHORT_BUFFER         (-12)  /* caller's dst / workspace too small */
+
+/* ---- enums (values fixed by the wire format) ---- */
+enum hb_codec   { HB_BLOSCLZ = 0, HB_LZ4 = 1, HB_LZ4HC = 2, HB_SNAPPY = 3, HB_ZLIB = 4, HB_ZSTD = 5 };   /* blosc.go:57-64 */
+enum hb_shuffle { HB_NOSHUFFLE = 0, HB_SHUFFLE = 1, HB_BITSHUFFLE = 2 };                                   /* blosc.go:89-93 */
+enum hb_filter_op { HB_OP_SHUFFLE = 0, HB_OP_UNSHUFFLE = 1, HB_OP_BITSHUFFLE = 2, HB_OP_BITUNSHUFFLE = 3 };
+/* header flag bits, blosc.go:110-115 */
+enum { HB_FLAG_SHUFFLE = 0x1, HB_FLAG_MEMCPY = 0x2, HB_FLAG_BITSHUFFLE = 0x4, HB_FLAG_SPLIT = 0x8 };
+#define HB_HEADER_SIZE 16          /* blosc.go:118-121 */
+#define HB_FORMAT_VERSION 2        /* blosc.go:51 */
+
+/* ---- compress-side option bits (`opts` argument) ---- */
+#define HB_OPT_INDEX_TRAILER     0x1u  /* append the restart index AFTER cbytes (ignored by the reference decoder, blosc.go:385-393);
+                                          lets hb_decompress_* decode the frame chunk-parallel */
+#define HB_OPT_REFERENCE_MEMCPY  0x2u  /* memcpy frames store the UN-filtered input exactly as blosc.go:342-345 does
+                                          (the reference then corrupts them on decode); default stores the
+                                          filtered bytes so the reference Decompress reproduces the input */
+
+/* 16-byte frame header, blosc.go:154-162 */
+typedef struct hb_header {
+    uint8_t  version;    /* 2 */
+    uint8_t  codec;      /* hb_codec ("VersionLZ") */
+    uint8_t  flags;
+    uint8_t  typesize;
+    uint32_t nbytes;     /* NBytesOrig */
+    uint32_t blocksize;  /* == nbytes */
+    uint32_t cbytes;     /* NBytesComp, header included */
+} hb_header;
+
+/* completion record of the asynchronous `_dev` entry points (lives in device or pinned memory) */
+typedef struct hb_result {
+    int32_t  status;        /* HB_OK or HB_ERR_* */
+    uint32_t flags;         /* frame flags byte (compress) / bit0: parallel index used (decompress) */
+    uint64_t bytes;         /* compress: frame bytes per the header (cbytes) or LZ4 block bytes; decompress: decoded bytes */
+    uint64_t total_bytes;   /* compress: bytes written to dst including the index trailer */
+    uint64_t reserved;
+} hb_result;
+
+/* ---- library / device ---- */
+int         hb_init(void);                 /* idempotent; HB_OK or HB_ERR_NO_DEVICE.  Replaces package init, shuffle.go:3-5 */
+int         hb_device_count(void);         /* 0 when no device */
+void        hb_shutdown(void);             /* frees cached workspaces */
+const char *hb_strerror(int code);
+const char *hb_version(void);
+
+/* pinned host buffers a Go caller can wrap with unsafe.Slice (avoids pageable staging) */
+void *hb_host_alloc(size_t bytes);
+void  hb_host_free(void *p);
+
+/* ---- filters: replace shuffleBytes / unshuffleBytes / bitShuffle / bitUnshuffle (shuffle.go:16-295)
+ *      and the SIMD hooks `func xxx(dst, src []byte, typeSize int) bool` (shuffle_amd64.go:21-41,
+ *      shuffle_generic.go:15-52).  COMPLETE semantics incl. tails; typesize<=1 || n<typesize -> plain copy.
+ *      dst and src must not overlap. ---- */
+int hb_filter(int op, void *dst, const void *src, size_t n, int typesize, int device);
+int hb_filter_dev(int op, void *d_dst, const void *d_src, size_t n, int typesize, void *stream);
+
+/* ---- LZ4 block codec: replaces lz4Codec.Compress / Decompress (codec.go:63-84), i.e. the
+ *      CodecInterface registered for blosc.LZ4 (codec.go:15-38) ---- */
+size_t  hb_lz4_bound(size_t n);                                                       /* lz4.CompressBlockBound, codec.go:65 */
+int64_t hb_lz4_compress(const void *src, size_t n, void *dst, size_t cap, int device);   /* -> bytes of ONE spec-valid LZ4 block */
+int64_t hb_lz4_decompress(const void *src, size_t n, void *dst, size_t cap, int device); /* -> decoded bytes (<= cap) */
+
+size_t  hb_lz4_compress_workspace(size_t n);
+size_t  hb_lz4_decompress_workspace(size_t n_out);
+/* async; d_index (may be NULL) receives the restart index for this block, index_cap bytes available (see hb_index_bound) */
+int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
+                        void *d_index, size_t index_cap,
+                        void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+/* async; d_index/index_bytes optional (NULL/0 -> serial single-wavefront decode) */
+int hb_lz4_decompress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
+                          const void *d_index, size_t index_bytes,
+                          void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+size_t  hb_index_bound(size_t n);   /* bytes of restart index for an n-byte block */
+
+/* ---- frame layer: replaces compressBackend / decompressBackend (blosc.go:320-434) behind
+ *      CompressWithOptions / DecompressWithSize (blosc.go:268-303) ---- */
+int     hb_parse_header(const void *frame, size_t n, hb_header *out);                 /* ParseHeader, blosc.go:165-185 */
+void    hb_header_bytes(const hb_header *h, void *out16);                             /* (*Header).Bytes, blosc.go:188-198 */
+size_t  hb_frame_bound(size_t n);                                                     /* 16 + lz4 bound + index trailer */
+/* returns bytes written to dst (cbytes, plus the trailer when HB_OPT_INDEX_TRAILER) */
+int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap,
+                          int codec, int level, int shuffle, int typesize,
+                          unsigned opts, int device);
+/* returns decoded bytes (== header nbytes); typesize_override <= 0 -> header typesize (blosc.go:417-419) */
+int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap,
+                            int typesize_override, int device);
+
+size_t  hb_compress_frame_workspace(size_t n);
+size_t  hb_decompress_frame_workspace(size_t n_out);
+int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap,
+                          int codec, int level, int shuffle, int typesize, unsigned opts,
+                          void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+/* `n` = bytes available at d_frame (>= cbytes; may include the trailer).  nbytes_hint = expected decoded size
+ * (cap of d_dst); the header is parsed on the device, no host round trip. */
+int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t cap,
+                            int typesize_override,
+                            void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+
+/* batch of independent frames, frame k -> device k mod hb_device_count(); per-frame results in rc[] */
+int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *n,
+                             void *const *dst, const size_t *cap, int64_t *rc,
+                             int codec, int level, int shuffle, int typesize, unsigned opts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPBLOSC_H */

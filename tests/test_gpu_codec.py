@@ -1,0 +1,241 @@
+"""GPU parity: LZ4 block codec and frame layer through the C ABI vs the CPU oracle.
+
+The reference pins no compressed bytes: what it pins are round trips, decoder
+rejections, header fields, error identities and a few inequalities (blosc_test.go, codec_test.go,
+example_test.go, fuzz_test.go).  Those are restated here, with the oracle decoder standing in for the
+reference's `Decompress` and liblz4 (when present) as an independent LZ4 block decoder.
+"""
+import ctypes
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _liblz4():
+    for p in ("/usr/lib/x86_64-linux-gnu/liblz4.so.1", "/opt/conda/lib/liblz4.so.1"):
+        if os.path.exists(p):
+            return ctypes.CDLL(p)
+    return None
+
+
+def _lz4_safe_decode(lz, c, n):
+    d = ctypes.create_string_buffer(max(n, 1))
+    r = lz.LZ4_decompress_safe(bytes(c), d, len(c), n)
+    return r, d.raw[:max(r, 0)]
+
+
+def _patterns(O):
+    rng = np.random.default_rng(5)
+    out = {
+        "mod256_10000": (np.arange(10000) % 256).astype(np.uint8),           # blosc_test.go:13-29
+        "mod64_1000": (np.arange(1000) % 64).astype(np.uint8),               # example_test.go:13-33
+        "zeros_10000": np.zeros(10000, np.uint8),                            # example_test.go:124-149
+        "f32_ramp": O.synth(O.D_RAMP, 25000),                                # blosc_test.go:107-134 / config 1
+        "f32_head": O.synth(O.D_F32, 1 << 16),
+        "f64_head": O.synth(O.D_F64, 1 << 15),
+        "i32_head": O.synth(O.D_I32, 1 << 16),
+        "rand_f32": O.synth(O.D_RAND, 1 << 14),
+        "random": rng.integers(0, 256, 50000, dtype=np.uint8),               # blosc_test.go:243-266
+        "bytes256_100000": O.synth(O.D_BYTES256, 100000),                    # blosc_test.go:363-371
+        "tiny_1": np.array([42], np.uint8),
+        "tiny_5": np.arange(5, dtype=np.uint8),
+        "tiny_13": np.arange(13, dtype=np.uint8),
+        "run_4095": np.full(4095, 7, np.uint8),
+        "run_4096": np.full(4096, 7, np.uint8),
+        "run_4097": np.full(4097, 7, np.uint8),
+        "run_70000": np.full(70000, 9, np.uint8),
+        "period3": np.tile(np.array([1, 2, 3], np.uint8), 9000),
+        "period100": np.tile(rng.integers(0, 256, 100, dtype=np.uint8), 700),
+        "mixed": np.concatenate([rng.integers(0, 256, 9000, dtype=np.uint8), np.zeros(9000, np.uint8),
+                                 rng.integers(0, 4, 9000, dtype=np.uint8), np.arange(9000, dtype=np.uint32).view(np.uint8)]),
+    }
+    return out
+
+
+def test_lz4_block_decodes_with_oracle_and_liblz4(hb, O):
+    codec = hb.HipLZ4Codec()
+    lz = _liblz4()
+    for name, x in _patterns(O).items():
+        c = codec.Compress(x.tobytes(), 5)
+        assert 0 < len(c) <= hb.lib().hb_lz4_bound(x.size), name
+        back = O.lz4_decompress(np.frombuffer(c, np.uint8), x.size)
+        assert np.array_equal(back, x), f"{name}: oracle decode of the device block differs"
+        if lz is not None:
+            r, d = _lz4_safe_decode(lz, c, x.size)
+            assert r == x.size and d == x.tobytes(), f"{name}: liblz4 rejects/differs ({r})"
+        assert codec.Decompress(c, x.size) == x.tobytes(), f"{name}: device decode of the device block differs"
+
+
+def test_lz4_device_decodes_oracle_blocks(hb, O):
+    # streams shaped like the reference's (no index): serial single-wavefront decoder
+    codec = hb.HipLZ4Codec()
+    for name, x in _patterns(O).items():
+        c = O.lz4_compress(x)
+        assert codec.Decompress(c.tobytes(), x.size) == x.tobytes(), name
+
+
+def test_lz4_encoder_is_deterministic(hb, O):
+    codec = hb.HipLZ4Codec()
+    x = O.filter(0, O.synth(O.D_F32, 1 << 18), 4).tobytes()
+    a = codec.Compress(x, 5)
+    for _ in range(3):
+        assert codec.Compress(x, 5) == a
+
+
+def test_lz4_decoder_rejections(hb):
+    # codec_test.go:203-233, :276-295: FF FF FF FF must fail; plus offset 0, offset beyond start,
+    # truncated stream, output overflow
+    codec = hb.HipLZ4Codec()
+    bad = [
+        (b"\xff\xff\xff\xff", 100),
+        (b"\x10A\x00\x00", 100),                 # offset 0
+        (b"\x10A\x05\x00", 100),                 # offset 5 with 1 byte produced
+        (b"\x40AB", 100),                        # 4 literals announced, 2 present
+        (b"\x10A\x01\x00", 3),                   # match of 4 overflows a 3-byte output
+        (b"\xf0", 100),                          # truncated length extension
+    ]
+    for stream, cap in bad:
+        with pytest.raises(hb.ErrDecompressionFailed):
+            codec.Decompress(stream, cap)
+    assert codec.Decompress(b"", 10) == b""       # UncompressBlock: empty src -> 0, nil
+    assert codec.Decompress(b"\x00", 10) == b""
+    assert codec.Decompress(b"\x10A\x01\x00", 100) == b"AAAAA"     # stream may end right after a match
+    assert codec.Decompress(b"\x30abc", 100) == b"abc"            # short output is not a codec error (codec.go:83)
+
+
+@pytest.mark.parametrize("shuffle,ts", [(0, 1), (1, 4), (2, 4), (1, 8), (2, 8), (1, 2), (1, 16), (2, 2), (1, 3)])
+def test_frame_round_trips(hb, O, shuffle, ts):
+    # blosc_test.go:13-163, :290-312; every device frame must decode through the reference decoder (oracle)
+    for name, x in _patterns(O).items():
+        for opts in (0, hb.OPT_INDEX_TRAILER):
+            f = hb.Compress(x.tobytes(), hb.LZ4, 5, shuffle, ts, opts=opts)
+            h = hb.ParseHeader(f)
+            assert (h.Version, h.VersionLZ, h.TypeSize, h.NBytesOrig, h.BlockSize) == (2, hb.LZ4, ts, x.size, x.size), name
+            assert h.ShuffleMode() == shuffle
+            if opts == 0:
+                assert h.NBytesComp == len(f)
+            else:
+                assert h.NBytesComp <= len(f)
+            assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), x), f"{name}: oracle decode differs"
+            assert hb.Decompress(f) == x.tobytes(), f"{name}: device decode differs"
+            assert hb.GetDecompressedSize(f) == x.size
+
+
+def test_device_decodes_oracle_frames(hb, O):
+    for name, x in _patterns(O).items():
+        for shuffle, ts in [(0, 1), (1, 4), (2, 4), (1, 8)]:
+            for policy in (0, O.POLICY_REFERENCE_MEMCPY):
+                f = O.compress_frame(x, shuffle=shuffle, typesize=ts, policy=policy)
+                want = O.decompress_frame(f)                  # bug-compatible for memcpy+filter frames (blosc.go:398-426)
+                assert hb.Decompress(f.tobytes()) == want.tobytes(), (name, shuffle, ts, policy)
+
+
+def test_header_and_inequalities(hb, O):
+    x = (np.arange(1000) % 64).astype(np.uint8).tobytes()
+    f = hb.Compress(x, hb.LZ4, 5, hb.Shuffle1, 4)
+    assert f[:12] == bytes([2, 1, 1, 4]) + struct.pack("<II", 1000, 1000)       # blosc_test.go:165-192, Appendix A
+    assert len(f) < len(x)                                                       # example_test.go:29-32
+    z = hb.Compress(bytes(10000), hb.LZ4, 5, hb.NoShuffle, 1)
+    assert hb.GetInfo(z).NBytesComp < 10000                                      # example_test.go:141-148
+    pat = np.tile(np.array([0x12, 0x34, 0x56, 0x78], np.uint8), 1000).tobytes()  # example_test.go:209-230 shape
+    pat = (np.arange(1000, dtype=np.uint32) * 1).view(np.uint8).tobytes()
+    assert len(hb.Compress(pat, hb.LZ4, 5, hb.Shuffle1, 4)) < len(hb.Compress(pat, hb.LZ4, 5, hb.NoShuffle, 4))
+    # memcpy frames: random bytes do not compress (blosc_test.go:243-266)
+    r = np.random.default_rng(1).integers(0, 256, 20000, dtype=np.uint8).tobytes()
+    fm = hb.Compress(r, hb.LZ4, 5, hb.NoShuffle, 1)
+    hm = hb.GetInfo(fm)
+    assert hm.IsMemcpy() and hm.NBytesComp == 16 + len(r) and fm[16:] == r
+    assert hb.Decompress(fm) == r
+
+
+def test_memcpy_policy(hb, O):
+    # incompressible input + filter.  Default: filtered bytes are stored, so the
+    # reference decoder reproduces the input; OPT_REFERENCE_MEMCPY restates blosc.go:342-345 bit for bit.
+    r = np.random.default_rng(2).integers(0, 256, 40000, dtype=np.uint8)
+    f = hb.Compress(r.tobytes(), hb.LZ4, 5, hb.Shuffle1, 4)
+    assert hb.GetInfo(f).IsMemcpy()
+    assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), r)
+    assert f == O.compress_frame(r, shuffle=1, typesize=4).tobytes()
+    g = hb.Compress(r.tobytes(), hb.LZ4, 5, hb.Shuffle1, 4, opts=hb.OPT_REFERENCE_MEMCPY)
+    assert g == O.compress_frame(r, shuffle=1, typesize=4, policy=O.POLICY_REFERENCE_MEMCPY).tobytes()
+    assert g[16:] == r.tobytes()
+    assert hb.Decompress(g) == O.decompress_frame(np.frombuffer(g, np.uint8)).tobytes() != r.tobytes()
+
+
+def test_errors(hb, O):
+    with pytest.raises(hb.ErrInvalidData):                      # blosc_test.go:211-215
+        hb.Compress(b"", hb.LZ4, 5, hb.NoShuffle, 1)
+    with pytest.raises(hb.ErrInvalidHeader):                    # blosc_test.go:217-225
+        hb.Decompress(b"\x02\x01\x00")
+    x = bytes(range(200)) * 5
+    f = bytearray(hb.Compress(x, hb.LZ4, 5, hb.NoShuffle, 1))
+    bad = bytearray(f); bad[0] = 99
+    with pytest.raises(hb.ErrInvalidVersion):                   # blosc_test.go:518-542
+        hb.Decompress(bytes(bad))
+    bad = bytearray(f); bad[1] = 77
+    with pytest.raises(hb.ErrInvalidCodec):                     # codec_test.go:37-58
+        hb.Decompress(bytes(bad))
+    with pytest.raises(hb.ErrInvalidCodec):
+        hb.Compress(x, 77, 5, hb.NoShuffle, 1)
+    bad = bytearray(f); bad[12:16] = struct.pack("<I", len(f) + 10)
+    with pytest.raises(hb.ErrInvalidData):                      # blosc_test.go:544-558
+        hb.Decompress(bytes(bad))
+    bad = bytearray(f); bad[12:16] = struct.pack("<I", 8)
+    with pytest.raises(hb.ErrInvalidData):
+        hb.Decompress(bytes(bad))
+    bad = bytearray(f); bad[4:8] = struct.pack("<I", 2000)      # NBytesOrig 1000 -> 2000, codec_test.go:60-79
+    with pytest.raises(hb.ErrSizeMismatch):
+        hb.Decompress(bytes(bad))
+    bad = bytearray(f); bad[4:8] = struct.pack("<I", 500)       # output overflow -> decode error
+    with pytest.raises(hb.ErrDecompressionFailed):
+        hb.Decompress(bytes(bad))
+    bad = bytearray(f)
+    for i in range(16, len(bad)):
+        bad[i] ^= 0xFF                                          # blosc_test.go:593-611
+    with pytest.raises(hb.BloscError):
+        hb.Decompress(bytes(bad))
+    assert hb.Decompress(bytes(f) + b"trailing garbage") == x   # bytes after cbytes are ignored, blosc.go:385-393
+
+
+def test_option_clamping(hb):
+    # blosc_test.go:613-655: level -5 / 100 and typeSize -1 / 0 are accepted
+    x = bytes(range(256)) * 8
+    for level in (-5, 0, 100):
+        assert hb.Decompress(hb.Compress(x, hb.LZ4, level, hb.Shuffle1, 4)) == x
+    for ts in (-1, 0):
+        f = hb.Compress(x, hb.LZ4, 5, hb.Shuffle1, ts)
+        assert hb.GetInfo(f).TypeSize == 1
+        assert hb.Decompress(f) == x
+    o = hb.DefaultOptions()
+    assert (o.Codec, o.Level, o.Shuffle, o.TypeSize, o.BlockSize) == (hb.LZ4, 5, hb.Shuffle1, 4, 0)
+    o.BlockSize, o.NumThreads = 12345, 8                        # accepted, ignored (blosc.go:232-233)
+    assert hb.Decompress(hb.CompressWithOptions(x, o)) == x
+
+
+def test_typesize_override_and_wide_typesize(hb, O):
+    x = O.synth(O.D_F32, 5000)
+    f = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.Shuffle1, 4)
+    assert hb.DecompressWithSize(f, 4) == x.tobytes()
+    assert hb.DecompressWithSize(f, 2) == O.decompress_frame(np.frombuffer(f, np.uint8), 2).tobytes()
+    # typeSize 256 is truncated to 0 in the header (blosc.go:362) -> no unshuffle on decode (Appendix D)
+    y = np.random.default_rng(9).integers(0, 3, 256 * 40, dtype=np.uint8)
+    g = hb.Compress(y.tobytes(), hb.LZ4, 5, hb.Shuffle1, 256)
+    assert hb.GetInfo(g).TypeSize == 0
+    assert hb.Decompress(g) == O.decompress_frame(np.frombuffer(g, np.uint8)).tobytes()
+
+
+def test_tampered_index_falls_back(hb, O):
+    # the restart index is never trusted: corrupting it must not change the decoded bytes
+    x = O.synth(O.D_F32, 1 << 16).tobytes()
+    f = bytearray(hb.Compress(x, hb.LZ4, 5, hb.Shuffle1, 4, opts=hb.OPT_INDEX_TRAILER))
+    cb = hb.GetInfo(bytes(f)).NBytesComp
+    ioff = (cb + 7) & ~7
+    assert len(f) > ioff + 32
+    for pos, val in [(ioff + 32 + 16 * 3, 0x55), (ioff + 32 + 16 * 5 + 8, 0x01), (ioff + 32 + 16 * 7 + 4, 0x10), (ioff + 8, 0x02)]:
+        g = bytearray(f)
+        g[pos] ^= val
+        assert hb.Decompress(bytes(g)) == x
