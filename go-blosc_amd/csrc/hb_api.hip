@@ -73,6 +73,8 @@ int select_device(int device) {
     return HB_OK;
 }
 
+thread_local unsigned g_last_flags = 0;   // hb_result.flags of the last host-pointer call on this thread
+
 bool overlap(const void *a, size_t na, const void *b, size_t nb) {
     const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
     return x < y + nb && y < x + na;
@@ -80,7 +82,42 @@ bool overlap(const void *a, size_t na, const void *b, size_t nb) {
 
 }  // namespace
 
+// ---- stage timing -------------------------------------------------------------------------
+namespace {
+struct ProfRec { const char *name; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}
+void hb_prof_begin(const char *stage, hipStream_t s) {
+    if (!g_prof_on) return;
+    ProfRec r{stage, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+void hb_prof_end(hipStream_t s) {
+    if (!g_prof_on || g_prof.empty()) return;
+    (void)hipEventRecord(g_prof.back().b, s);
+}
+
 extern "C" {
+
+// bench-only: single-threaded use.  enable(1) clears the log and starts recording one (stage, ms) per kernel launch.
+int hb_profile_enable(int on) {
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return HB_OK;
+}
+int hb_profile_count(void) { return (int)g_prof.size(); }
+// returns the stage name (static string) and its duration in ms; synchronises on the stage's end event
+const char *hb_profile_get(int i, float *ms) {
+    if (i < 0 || i >= (int)g_prof.size()) return nullptr;
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) t = -1.f;
+    if (ms) *ms = t;
+    return g_prof[i].name;
+}
 
 int hb_init(void) {
     std::call_once(g_once, do_init);
@@ -101,6 +138,7 @@ void hb_shutdown(void) {
 }
 
 const char *hb_version(void) { return HB_VERSION_STRING; }
+unsigned hb_last_result_flags(void) { return g_last_flags; }
 
 const char *hb_strerror(int code) {
     switch (code) {
@@ -382,6 +420,7 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     if (rc) return rc;
     hb_result r;
     HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    g_last_flags = r.flags;
     if (r.status) return r.status;
     if (r.bytes) HB_HIP_TRY(hipMemcpy(dst, d_dst, r.bytes, hipMemcpyDeviceToHost));
     return (int64_t)r.bytes;

@@ -58,5 +58,9 @@ __device__ __forceinline__ uint64_t bit_transpose8x8_msb(uint64_t x) {
 
 #define HB_HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return HB_ERR_HIP; } while (0)
 
+// ---- stage timing for bench.py (hb_profile_*): HIP events on the launch stream around each kernel ----
+void hb_prof_begin(const char *stage, hipStream_t s);   // no-ops unless hb_profile_enable(1)
+void hb_prof_end(hipStream_t s);
+
 // ---- internal launch API shared between translation units ----
 int hb_launch_filter(int op, uint8_t *d_dst, const uint8_t *d_src, size_t n, int typesize, hipStream_t s);

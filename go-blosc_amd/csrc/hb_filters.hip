@@ -217,8 +217,16 @@ static void launch_shuffle_vec(bool inverse, uint8_t *dst, const uint8_t *src, u
     else hipLaunchKernelGGL(k_unshuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles);
 }
 
+static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, hipStream_t s);
 int hb_launch_filter(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, hipStream_t s) {
+    static const char *names[4] = {"filter_shuffle", "filter_unshuffle", "filter_bitshuffle", "filter_bitunshuffle"};
     if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
+    hb_prof_begin(names[op], s);
+    const int rc = launch_filter_impl(op, dst, src, n, typesize, s);
+    hb_prof_end(s);
+    return rc;
+}
+static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, hipStream_t s) {
     if (n == 0) return HB_OK;
     if (typesize <= 1 || n < (size_t)typesize) {        // shuffle.go:17-19 etc.: identity
         HB_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));

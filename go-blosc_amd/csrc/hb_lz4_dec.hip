@@ -50,8 +50,30 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
     plan->mode = DEC_INDEXED;
 }
 
-#define DEC_IN_MAX  (HB_CHUNK + 256u)    // largest stream slice a unit may have
+#define DEC_IN_MAX  (HB_CHUNK + 512u)    // bytes of a unit's stream slice that are staged in LDS
 #define DEC_OUT_MAX HB_CHUNK             // largest output a unit may have
+
+// Sum of an LZ4 length extension (bytes 255 ... 255 r) starting at slice offset si, read cooperatively 64 bytes
+// at a time; bytes beyond the staged window come straight from HBM (a literal run of many MiB has an
+// extension of tens of KiB).  Returns false when the extension runs off the slice or is absurdly long.
+__device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged, const uint8_t *g, uint32_t slen,
+                                             uint32_t &si, uint32_t &acc, int lane) {
+    uint64_t sum = acc;
+    for (;;) {
+        const uint32_t i = si + lane;
+        uint32_t b = 0;                                   // out of range reads as a terminator
+        if (i < slen) b = (i < staged) ? in[i] : g[i];
+        const unsigned long long stop = __ballot(b != 255u);
+        if (stop == 0) { sum += 255u * 64u; si += 64; if (sum > 0xFFFFFFF0ull) return false; continue; }
+        const int f = __builtin_ctzll(stop);
+        if (si + (uint32_t)f >= slen) return false;
+        sum += 255u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane(b, f);
+        si += (uint32_t)f + 1;
+        if (sum > 0xFFFFFFF0ull) return false;
+        acc = (uint32_t)sum;
+        return true;
+    }
+}
 
 __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
@@ -62,26 +84,25 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
     const int lane = threadIdx.x;
     const uint32_t nunits = plan->nunits;
     const uint8_t *ent = index + HB_IDX_HDR_BYTES;
-    const uint32_t nbytes = ld32(index + 20);
+    const uint32_t nbytes = plan->nbytes;
 
     for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
-        const uint32_t s0 = ld32(ent + 16 * (size_t)u), d0 = ld32(ent + 16 * (size_t)u + 4);
-        uint32_t rem = ld32(ent + 16 * (size_t)u + 8);
-        uint32_t tokpos = ld32(ent + 16 * (size_t)u + 12);
-        const uint32_t s1 = ld32(ent + 16 * (size_t)(u + 1)), d1 = ld32(ent + 16 * (size_t)(u + 1) + 4);
-        const uint32_t rem1 = ld32(ent + 16 * (size_t)(u + 1) + 8), tok1 = ld32(ent + 16 * (size_t)(u + 1) + 12);
+        const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
+        const uint32_t s0 = e0.x, d0 = e0.y, s1 = e1.x, d1 = e1.y, rem1 = e1.z, tok1 = e1.w;
+        uint32_t rem = e0.z, tokpos = e0.w;
         const bool last = (u + 1 == nunits);
-        bool ok = s0 <= s1 && s1 <= n_src && d0 <= d1 && d1 <= nbytes && (s1 - s0) <= DEC_IN_MAX && (d1 - d0) <= DEC_OUT_MAX;
+        bool ok = s0 <= s1 && s1 <= n_src && d0 <= d1 && d1 <= nbytes && (d1 - d0) <= DEC_OUT_MAX;
         if (u == 0) ok = ok && s0 == 0 && d0 == 0 && rem == HB_IDX_AT_TOKEN;
         if (last) ok = ok && s1 == n_src && d1 == nbytes;
         if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
         const uint32_t slen = s1 - s0, outlen = d1 - d0;
-        // stage the slice
+        // stage the head of the slice (all of it, normally)
         const uint8_t *g = src + s0;
         const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
+        const uint32_t staged = slen < DEC_IN_MAX - 16u ? slen : DEC_IN_MAX - 16u;
         {
             const u32x4 *ga = (const u32x4 *)(g - sh);
-            const uint32_t nv = (sh + slen + 15u) >> 4;
+            const uint32_t nv = (sh + staged + 15u) >> 4;
             for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_in)[i] = ga[i];
         }
         uint32_t tok = 0;
@@ -90,36 +111,38 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         const uint8_t *in = s_in + sh;
         uint32_t si = 0, di = 0;
         bool at_token = false;       // state when the unit stops
-        if (rem == HB_IDX_AT_TOKEN) { rem = 0; goto parse_token; }
-        for (;;) {
+        bool need_token = (rem == HB_IDX_AT_TOKEN);
+        if (need_token) rem = 0;
+        while (ok) {
+            if (need_token) {
+                if (si >= slen) { ok = false; break; }
+                tokpos = s0 + si;
+                tok = (si < staged) ? in[si] : g[si];
+                si++;
+                rem = tok >> 4;
+                if (rem == 15u && !dec_read_ext(in, staged, g, slen, si, rem, lane)) { ok = false; break; }
+                need_token = false;
+            }
             {   // literal phase
                 const uint32_t take = min(rem, outlen - di);
                 if (take > slen - si) { ok = false; break; }
-                for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = in[si + i];
+                if (si + take <= staged) { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = in[si + i]; }
+                else { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = g[si + i]; }
                 si += take; di += take; rem -= take;
             }
             if (rem > 0 || di == outlen) { at_token = false; break; }
             {   // match phase
-                if (si == slen) { ok = false; break; }            // block ends after literals: short output -> serial decides
-                if (slen - si < 2) { ok = false; break; }
-                const uint32_t offset = (uint32_t)in[si] | ((uint32_t)in[si + 1] << 8);
+                if (slen - si < 2) { ok = false; break; }         // also: block ends after literals -> serial decides
+                const uint32_t b0 = (si < staged) ? in[si] : g[si], b1 = (si + 1 < staged) ? in[si + 1] : g[si + 1];
+                const uint32_t offset = b0 | (b1 << 8);
                 si += 2;
                 uint32_t mlen = (tok & 15u) + 4u;
-                if ((tok & 15u) == 15u) {
-                    for (;;) {
-                        if (si >= slen) { ok = false; break; }
-                        const uint32_t b = in[si++];
-                        mlen += b;
-                        if (b != 255u) break;
-                        if (mlen > DEC_OUT_MAX + 4u) { ok = false; break; }
-                    }
-                    if (!ok) break;
-                }
+                if ((tok & 15u) == 15u && !dec_read_ext(in, staged, g, slen, si, mlen, lane)) { ok = false; break; }
                 if (offset == 0 || offset > di || mlen > outlen - di) { ok = false; break; }
                 wave_sync();                                       // earlier s_out writes visible
                 if (offset >= 64u) {
-                    for (uint32_t b0 = 0; b0 < mlen; b0 += 64) {
-                        const uint32_t i = b0 + lane;
+                    for (uint32_t c0 = 0; c0 < mlen; c0 += 64) {
+                        const uint32_t i = c0 + lane;
                         uint8_t v = 0;
                         if (i < mlen) v = s_out[di + i - offset];
                         if (i < mlen) s_out[di + i] = v;
@@ -128,8 +151,8 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                 } else {
                     uint32_t m = (uint32_t)lane % offset;          // source is always inside [di-offset, di)
                     const uint32_t step = 64u % offset;
-                    for (uint32_t b0 = 0; b0 < mlen; b0 += 64) {
-                        const uint32_t i = b0 + lane;
+                    for (uint32_t c0 = 0; c0 < mlen; c0 += 64) {
+                        const uint32_t i = c0 + lane;
                         if (i < mlen) s_out[di + i] = s_out[di - offset + m];
                         m += step; if (m >= offset) m -= offset;
                     }
@@ -137,19 +160,7 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                 di += mlen;
             }
             if (si == slen || di == outlen) { at_token = true; break; }
-        parse_token:
-            tokpos = s0 + si;
-            tok = in[si++];
-            rem = tok >> 4;
-            if (rem == 15u) {
-                for (;;) {
-                    if (si >= slen) { ok = false; break; }
-                    const uint32_t b = in[si++];
-                    rem += b;
-                    if (b != 255u) break;
-                }
-                if (!ok) break;
-            }
+            need_token = true;
         }
         // end-state check against the next entry
         if (ok) {
@@ -292,15 +303,21 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
         return HB_OK;
     }
     DecPlan *plan = (DecPlan *)a.work;
+    hb_prof_begin("k_dec_plan", s);
     hipLaunchKernelGGL(k_dec_plan, dim3(1), dim3(1), 0, s, a.index, (uint64_t)a.index_bytes, (uint64_t)a.n,
                        (uint64_t)a.cap, plan, a.result);
+    hb_prof_end(s);
     if (a.index) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
         const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u ? units : 256u * 64u));
+        hb_prof_begin("k_dec_indexed", s);
         hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan);
+        hb_prof_end(s);
     }
+    hb_prof_begin("k_dec_serial", s);
     hipLaunchKernelGGL(k_dec_serial, dim3(1), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (uint64_t)a.cap, plan,
                        a.result, a.frame, a.expect);
+    hb_prof_end(s);
     HB_HIP_TRY(hipGetLastError());
     return HB_OK;
 }

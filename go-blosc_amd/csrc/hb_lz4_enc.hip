@@ -429,15 +429,24 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
 
     if (L.nchunks) {
         const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;
+        hb_prof_begin("k_match", s);
         hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks);
+        hb_prof_end(s);
+        hb_prof_begin("k_tiles", s);
         hipLaunchKernelGGL(k_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg, tile_nf);
+        hb_prof_end(s);
     }
+    hb_prof_begin("k_scan", s);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, s, tile_agg, tile_nf, tile_pre, tile_suf, L.ntiles, L.nchunks,
                        (uint64_t)a.n, plan, a.dst, fi, a.result, has_index);
-    if (L.nchunks)
+    hb_prof_end(s);
+    if (L.nchunks) {
+        hb_prof_begin("k_stitch", s);
         hipLaunchKernelGGL(k_stitch, dim3(L.ntiles), dim3(256), 0, s, desc, records, tile_pre, tile_suf, plan, L.nchunks,
                            (uint64_t)a.n, out, a.frame ? (uint8_t *)nullptr : a.index, a.frame ? a.dst : (uint8_t *)nullptr,
                            a.memcpy_src);
+        hb_prof_end(s);
+    }
     HB_HIP_TRY(hipGetLastError());
     return HB_OK;
 }

@@ -87,6 +87,7 @@ EXPORTS = [
     "hb_index_bound", "hb_parse_header", "hb_header_bytes", "hb_frame_bound", "hb_compress_frame",
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi",
+    "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
 ]
 
 
@@ -134,6 +135,9 @@ def lib():
             "hb_compress_frame_dev": (i32, [vp, sz, vp, sz, i32, i32, i32, i32, u32, vp, sz, vp, vp]),
             "hb_decompress_frame_dev": (i32, [vp, sz, vp, sz, i32, vp, sz, vp, vp]),
             "hb_compress_frames_multi": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, u32]),
+            "hb_last_result_flags": (u32, []),
+            "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
+            "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)

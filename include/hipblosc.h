@@ -87,6 +87,14 @@ int         hb_device_count(void);         /* 0 when no device */
 void        hb_shutdown(void);             /* frees cached workspaces */
 const char *hb_strerror(int code);
 const char *hb_version(void);
+unsigned    hb_last_result_flags(void);    /* hb_result.flags of the last host-pointer frame decode on this thread
+                                              (bit0: the restart index was used) — diagnostics for tests */
+
+/* stage timing for the bench harness (single-threaded use): with enable(1) every kernel stage launched by the
+ * `_dev` entry points is bracketed by HIP events on its stream; get(i) returns the stage name and its ms. */
+int         hb_profile_enable(int on);
+int         hb_profile_count(void);
+const char *hb_profile_get(int i, float *ms);
 
 /* pinned host buffers a Go caller can wrap with unsafe.Slice (avoids pageable staging) */
 void *hb_host_alloc(size_t bytes);

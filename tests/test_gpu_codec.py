@@ -239,3 +239,26 @@ def test_tampered_index_falls_back(hb, O):
         g = bytearray(f)
         g[pos] ^= val
         assert hb.Decompress(bytes(g)) == x
+
+
+def test_multi_tile_frames_use_the_index(hb, O):
+    # several scan tiles (256 chunks each), literal runs of MiB (255-extension of tens of KiB), ragged ends;
+    # the indexed decoder must accept its own index (flag bit0), not silently fall back to the serial one
+    rng = np.random.default_rng(11)
+    cases = {
+        "f32_5MiB": (O.synth(O.D_F32, (5 << 20) // 4 + 3), 1, 4),
+        "f64_3MiB": (O.synth(O.D_F64, (3 << 20) // 8 + 1), 1, 8),
+        "i32_bitshuffle_3MiB": (O.synth(O.D_I32, (3 << 20) // 4), 2, 4),
+        "rand_then_zeros": (np.concatenate([rng.integers(0, 256, (2 << 20) + 77, dtype=np.uint8), np.zeros(1 << 20, np.uint8),
+                                            rng.integers(0, 256, 123457, dtype=np.uint8), np.full(70001, 3, np.uint8)]), 0, 1),
+        "ramp_2MiB": (O.synth(O.D_RAMP, (2 << 20) // 4 + 5), 1, 4),
+    }
+    for name, (x, shuffle, ts) in cases.items():
+        f = hb.Compress(x.tobytes(), hb.LZ4, 5, shuffle, ts, opts=hb.OPT_INDEX_TRAILER)
+        assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), x), f"{name}: oracle decode differs"
+        assert hb.Decompress(f) == x.tobytes(), f"{name}: device decode differs"
+        if not hb.GetInfo(f).IsMemcpy():
+            assert hb.lib().hb_last_result_flags() & 1, f"{name}: indexed decoder rejected its own index"
+        cb = hb.GetInfo(f).NBytesComp
+        assert hb.Decompress(f[:cb]) == x.tobytes(), f"{name}: serial decode (index cut off) differs"
+        assert not (hb.lib().hb_last_result_flags() & 1)
