@@ -4,14 +4,20 @@
 // The reference decodes a frame payload with ONE UncompressBlock call (codec.go:79), so the output has to
 // be one spec-valid LZ4 block.  A block is a serial chain of sequences; it is built in parallel like this:
 //
-//   k_match  : one wavefront per 4 KiB chunk.  The chunk sits in LDS; every step the 64 lanes hash the 4
-//              bytes at 64 consecutive positions, probe/insert a 2048-entry u16 table in LDS, verify the
-//              candidates, and the wave then walks the hits in order (ballot + readlane), extending each
-//              match cooperatively (64 byte compares per step).  Matches never leave the chunk, the last 5
-//              bytes of a chunk stay literals and no match starts in its last 12 (LZ4 end-of-block rules,
-//              applied per chunk so that the very last chunk satisfies them).  The wave emits its sequences
-//              into an LDS buffer and flushes them as one coalesced record:
-//                  [lead literals][rest of sequence 0][sequence 1]...[sequence m-1][trailing literals]
+//   k_match  : one wavefront per 4 KiB chunk, chunk resident in LDS.  Every step the 64 lanes look at 64
+//              consecutive positions: hash the 4 bytes there, probe / insert a 1024-entry u16 table in LDS,
+//              verify the candidate, fall back to the offset-1 (run) candidate, and extend their own match
+//              by up to 8 more bytes.  Positions inside a run of equal 4-grams are not inserted, so the
+//              table keeps run STARTS (a candidate at the end of a run cannot be extended).  The wave then
+//              walks the hits in position order with scalar code only (ballot / readlane / writelane);
+//              matches that are still going after 12 bytes are extended cooperatively, 256 bytes per step.
+//              Sequences are queued one per lane and emitted 64 at a time, lane-parallel: sizes -> wave
+//              prefix sum -> every lane writes its own token / extension / literals / offset into an LDS
+//              image of the record, which is flushed with coalesced 16-byte stores.  After 4 steps without
+//              a hit the scan strides over 64-byte gaps (LZ4's skip acceleration).  Matches never leave
+//              the chunk; the last 5 bytes of a chunk stay literals and no match starts in its last 12
+//              (LZ4 end-of-block rules, applied per chunk so the very last chunk satisfies them).
+//              Record:  [lead literals][rest of sequence 0][sequence 1]...[sequence m-1]
 //              Sequence 0 has no token yet: its literal run also contains whatever the previous chunks
 //              left un-matched, which only the scan knows.
 //   k_tiles, k_scan : an associative scan over chunk summaries (has-match, first match position F, bytes,
@@ -19,19 +25,21 @@
 //              literal run that closes it; a suffix scan gives the position of the NEXT match (the header
 //              of a literal run depends on its total length, which is only known at its end).
 //   k_stitch : every chunk writes exactly the bytes it owns in the final block: its segment header
-//              (token + 255-extension), its encoded bytes, and its trailing literals at their place inside
-//              the literal run that a later chunk (or the end of the block) closes.  Also writes the frame
-//              header / memcpy fallback (blosc.go:342-371) and the restart index.
+//              (token + 255-extension), its encoded bytes (from the record), and its trailing literals
+//              (from the source) at their place inside the literal run that a later chunk (or the end of
+//              the block) closes.  Also the memcpy fallback (blosc.go:342-345) and the restart index.
 //
-// Algorithmic HBM bytes: n (read) + C (write).  The records cost another ~n written + ~n read; see DESIGN.md.
+// Algorithmic HBM bytes: n (read) + C (write).  Extra traffic: records (~C written + read) and the literal
+// bytes of the source read a second time by k_stitch; see DESIGN.md.
 #include "hb_lz4.h"
 
-#define HLOG 11
+#define HLOG 10
 #define HSIZE (1u << HLOG)
+#define LITCAP 16u          // literal runs up to this long are copied by the owning lane, longer ones by the wave
 
 struct __attribute__((aligned(16))) ChunkDesc {
     uint32_t lead;      // literals before the first match (chunk-relative)
-    uint32_t enc_len;   // record bytes before the trailing literals (lead + encoded sequences)
+    uint32_t enc_len;   // record bytes (lead literals + encoded sequences)
     uint32_t last_end;  // chunk-relative end of the last match; 0 = chunk has no match
     uint32_t mcode0;    // match-length nibble of sequence 0
 };
@@ -69,7 +77,7 @@ struct EncPlan {
     uint64_t cbytes_block;   // LZ4 block bytes
     uint32_t use_memcpy;
     uint32_t nchunks;
-    uint64_t index_off;      // byte offset of the index from dst (frame) or 0 (external buffer)
+    uint64_t index_off;      // byte offset of the index from the frame start (0: none / external buffer)
     uint64_t pad[4];
 };
 
@@ -108,6 +116,15 @@ __device__ __forceinline__ uint32_t lds_read4(const uint8_t *base, uint32_t a) {
     return __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
 }
 
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
                                               uint32_t nchunks) {
@@ -131,71 +148,135 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
         }
         wave_sync();
 
-        int pos = 0, anchor = 0, o = 0, nseq = 0;
-        uint32_t lead = 0, mcode0 = 0;
-        const int mstart_max = len - 12;     // last position a match may start at
-        const int mend_max = len - 5;        // matches end at or before this
+        int pos = 0, anchor = 0, o = 0, nq = 0, nseq = 0, miss = 0;
+        uint32_t q_mp = 0, q_ml = 0, q_off = 0;          // lane i: i-th queued sequence
+        uint32_t batch_anchor = 0, lead = 0, mcode0 = 0;
+        const int mstart_max = len - 12;                  // last position a match may start at
+        const int mend_max = len - 5;                     // matches end at or before this
+
+        // emit the queued sequences, one per lane
+        auto flush = [&]() {
+            const bool act = lane < nq;
+            const uint32_t end = q_mp + q_ml;
+            uint32_t prev = __shfl_up(end, 1);
+            if (lane == 0) prev = batch_anchor;
+            const uint32_t lit = q_mp - prev, mcode = q_ml - 4u;
+            const bool first = (nseq == 0) && lane == 0;  // sequence 0 of the chunk: token comes from k_stitch
+            const uint32_t nbl = first ? 0u : lz4_ext_bytes(lit), nbm = lz4_ext_bytes(mcode);
+            const uint32_t size = act ? ((first ? 0u : 1u) + nbl + lit + 2u + nbm) : 0u;
+            const uint32_t incl = wave_incl_scan(size, lane);
+            uint32_t q = (uint32_t)o + incl - size;
+            uint32_t litdst = 0;
+            if (act) {
+                if (!first) {
+                    s_out[q++] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+                    if (nbl) {
+                        for (uint32_t k = 0; k + 1 < nbl; k++) s_out[q++] = 255;
+                        s_out[q++] = (uint8_t)((lit - 15u) - 255u * (nbl - 1));
+                    }
+                }
+                litdst = q;
+                if (lit <= LITCAP) for (uint32_t k = 0; k < lit; k++) s_out[q + k] = s_data[sh + prev + k];
+                q += lit;
+                s_out[q] = (uint8_t)q_off; s_out[q + 1] = (uint8_t)(q_off >> 8);
+                q += 2;
+                if (nbm) {
+                    for (uint32_t k = 0; k + 1 < nbm; k++) s_out[q++] = 255;
+                    s_out[q++] = (uint8_t)((mcode - 15u) - 255u * (nbm - 1));
+                }
+            }
+            unsigned long long lm = __ballot(act && lit > LITCAP);
+            while (lm) {                                   // long literal runs: the whole wave copies
+                const int l = __builtin_ctzll(lm);
+                const uint32_t s = __builtin_amdgcn_readlane(prev, l), dq = __builtin_amdgcn_readlane(litdst, l);
+                const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
+                for (uint32_t k = lane; k < ln; k += 64) s_out[dq + k] = s_data[sh + s + k];
+                lm &= lm - 1;
+            }
+            if (nseq == 0) {
+                lead = __builtin_amdgcn_readlane(lit, 0);
+                const uint32_t m0 = __builtin_amdgcn_readlane(mcode, 0);
+                mcode0 = m0 < 15u ? m0 : 15u;
+            }
+            o += (int)__builtin_amdgcn_readlane(incl, 63);
+            batch_anchor = __builtin_amdgcn_readlane(end, nq - 1);
+            nseq += nq;
+            nq = 0;
+        };
+
         while (pos <= mstart_max) {
             const int p = pos + lane;
-            const uint32_t v = lds_read4(s_data, sh + (uint32_t)p);
+            const uint32_t a = sh + (uint32_t)p;
+            const uint32_t v = lds_read4(s_data, a);
+            const uint32_t vprev = lds_read4(s_data, a ? a - 1 : 0);
             const bool valid = p <= mstart_max;
+            const bool rle = valid && p >= 1 && vprev == v;          // inside a run of equal 4-grams
             const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
-            const uint32_t cand = s_tab[h];
-            wave_sync();
-            if (valid) s_tab[h] = (uint16_t)p;
+            uint32_t cand = s_tab[h];
+            if (valid && !rle) s_tab[h] = (uint16_t)p;
             const uint32_t cv = lds_read4(s_data, sh + cand);
-            const bool ism = valid && (int)cand < p && cv == v;
+            const bool hit = valid && (int)cand < p && cv == v;
+            if (!hit && rle) cand = (uint32_t)p - 1u;
+            const bool ism = hit || rle;
             unsigned long long mask = __ballot(ism);
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                const int mp = pos + l;
-                const int mc = (int)__builtin_amdgcn_readlane(cand, l);
-                // cooperative forward extension
-                int mlen = 4;
-                const int maxl = mend_max - mp;
-                for (;;) {
-                    const int i = mlen + lane;
-                    const bool ne = (i >= maxl) || s_data[sh + mp + i] != s_data[sh + mc + i];
-                    const unsigned long long m2 = __ballot(ne);
-                    if (m2) { mlen += __builtin_ctzll(m2); break; }
-                    mlen += 64;
+            if (mask) {
+                // every lane extends its own match to at most 12 bytes
+                uint32_t ml = 4;
+                bool lng = false;
+                if (ism) {
+                    const uint32_t x = lds_read4(s_data, a + 4) ^ lds_read4(s_data, sh + cand + 4);
+                    if (x) ml = 4u + ((uint32_t)__builtin_ctz(x) >> 3);
+                    else {
+                        const uint32_t y = lds_read4(s_data, a + 8) ^ lds_read4(s_data, sh + cand + 8);
+                        if (y) ml = 8u + ((uint32_t)__builtin_ctz(y) >> 3);
+                        else { ml = 12; lng = true; }
+                    }
+                    const uint32_t maxl = (uint32_t)(mend_max - p);
+                    if (ml >= maxl) { ml = maxl; lng = false; }
                 }
-                // emit [token][litlen ext][literals][offset][matchlen ext]; sequence 0 has no token yet
-                const int lit = mp - anchor;
-                const uint32_t mcode = (uint32_t)(mlen - 4);
-                if (nseq == 0) { lead = (uint32_t)lit; mcode0 = mcode < 15u ? mcode : 15u; }
-                else {
-                    const uint32_t nb = lz4_ext_bytes((uint32_t)lit);
-                    if (lane == 0) s_out[o] = (uint8_t)((((uint32_t)lit < 15u ? (uint32_t)lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
-                    if ((uint32_t)lane < nb)
-                        s_out[o + 1 + lane] = ((uint32_t)lane + 1 < nb) ? 255 : (uint8_t)(((uint32_t)lit - 15u) - 255u * (nb - 1));
-                    o += 1 + (int)nb;
+                const unsigned long long lmask = __ballot(lng);
+                while (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    const int mp = pos + l;
+                    const int mc = (int)__builtin_amdgcn_readlane(cand, l);
+                    int mlen = (int)__builtin_amdgcn_readlane(ml, l);
+                    if ((lmask >> l) & 1ull) {             // still matching after 12 bytes: 256 bytes per step
+                        const int maxl = mend_max - mp;
+                        for (;;) {
+                            const int i = mlen + 4 * lane;
+                            const int ic = i < maxl ? i : maxl;        // keep the reads inside the chunk image
+                            const uint32_t x = lds_read4(s_data, sh + (uint32_t)(mp + ic)) ^ lds_read4(s_data, sh + (uint32_t)(mc + ic));
+                            int eq = x ? (__builtin_ctz(x) >> 3) : 4;
+                            const int avail = maxl - i;
+                            if (avail < eq) eq = avail > 0 ? avail : 0;
+                            const bool full = (eq == 4);
+                            const unsigned long long part = __ballot(!full);
+                            if (part) {
+                                const int f = __builtin_ctzll(part);
+                                mlen += 4 * f + (int)__builtin_amdgcn_readlane((uint32_t)eq, f);
+                                break;
+                            }
+                            mlen += 256;
+                        }
+                    }
+                    if (lane == nq) { q_mp = (uint32_t)mp; q_ml = (uint32_t)mlen; q_off = (uint32_t)(mp - mc); }
+                    nq++;
+                    anchor = mp + mlen;
+                    if (nq == 64) flush();
+                    const int rel = anchor - pos;
+                    mask = rel >= 64 ? 0ull : (mask & (~0ull << rel));
                 }
-                for (int i = lane; i < lit; i += 64) s_out[o + i] = s_data[sh + anchor + i];
-                o += lit;
-                const uint32_t off = (uint32_t)(mp - mc);
-                if (lane < 2) s_out[o + lane] = (uint8_t)(off >> (8 * lane));
-                o += 2;
-                {
-                    const uint32_t nb = lz4_ext_bytes(mcode);
-                    if ((uint32_t)lane < nb)
-                        s_out[o + lane] = ((uint32_t)lane + 1 < nb) ? 255 : (uint8_t)((mcode - 15u) - 255u * (nb - 1));
-                    o += (int)nb;
-                }
-                nseq++;
-                anchor = mp + mlen;
-                const int rel = anchor - pos;
-                mask = rel >= 64 ? 0ull : (mask & (~0ull << rel));
+                miss = 0;
+            } else {
+                miss++;
             }
-            pos = anchor > pos + 64 ? anchor : pos + 64;
+            const int nxt = pos + 64 + ((miss >> 2) << 6);
+            pos = anchor > nxt ? anchor : nxt;
         }
-        // trailing literals, raw
-        const int trail = len - anchor;
-        for (int i = lane; i < trail; i += 64) s_out[o + i] = s_data[sh + anchor + i];
+        if (nq) flush();
         wave_sync();
-        const int total = o + trail;
         uint8_t *rec = records + (size_t)ck * HB_RSTRIDE;
-        for (int i = lane * 16; i < total; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_out + i);
+        for (int i = lane * 16; i < o; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_out + i);
         if (lane == 0) {
             ChunkDesc d;
             d.lead = nseq ? lead : 0u; d.enc_len = nseq ? (uint32_t)o : 0u;
@@ -209,13 +290,13 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 // ----------------------------------------------------------------------------------------------
 // scans
 // ----------------------------------------------------------------------------------------------
-// inclusive scan of 256 Aggs in LDS (Hillis-Steele, ordered)
+// inclusive scan of 256 Aggs in LDS (Hillis-Steele, ordered); threads >= 256 only take part in the barriers
 __device__ __forceinline__ void block_scan_agg(Agg *s, int t) {
     for (int d = 1; d < 256; d <<= 1) {
-        Agg x = s[t];
-        Agg y = (t >= d) ? s[t - d] : agg_identity();
+        Agg x = agg_identity(), y = agg_identity();
+        if (t < 256) { x = s[t]; if (t >= d) y = s[t - d]; }
         __syncthreads();
-        s[t] = agg_combine(y, x);
+        if (t < 256) s[t] = agg_combine(y, x);
         __syncthreads();
     }
 }
@@ -324,41 +405,45 @@ __global__ __launch_bounds__(256) void k_scan(const Agg *__restrict__ tile_agg, 
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_stitch: one workgroup per tile of 256 chunks; wave w places chunks w, w+4, ...
+// k_stitch: one workgroup (16 waves) per tile of 256 chunks; wave w places chunks w, w+16, ...
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stitch(const ChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records,
-                                                const Agg *__restrict__ tile_pre, const uint32_t *__restrict__ tile_suf,
-                                                const EncPlan *__restrict__ plan, uint32_t nchunks, uint64_t n,
-                                                uint8_t *__restrict__ out /* block start */,
-                                                uint8_t *__restrict__ index_base_ext, uint8_t *__restrict__ frame_base,
-                                                const uint8_t *__restrict__ memcpy_src) {
+#define STITCH_THREADS 1024
+__global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
+        const ChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records, const uint8_t *__restrict__ src,
+        const Agg *__restrict__ tile_pre, const uint32_t *__restrict__ tile_suf, const EncPlan *__restrict__ plan,
+        uint32_t nchunks, uint64_t n, uint8_t *__restrict__ out /* block start */,
+        uint8_t *__restrict__ index_base_ext, uint8_t *__restrict__ frame_base, const uint8_t *__restrict__ memcpy_src) {
     __shared__ Agg s[256];
     __shared__ uint32_t s_nf[256];
     __shared__ ChunkDesc s_desc[256];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    constexpr int NW = STITCH_THREADS / 64;
     const uint32_t ck0 = blockIdx.x * HB_TILE_CHUNKS;
     const uint32_t cnt = min(HB_TILE_CHUNKS, nchunks - ck0);
 
     if (plan->use_memcpy) {                                           // blosc.go:343-345: payload = (filtered) input
         const uint64_t b0 = (uint64_t)ck0 * HB_CHUNK;
         const uint64_t b1 = min((uint64_t)(ck0 + cnt) * HB_CHUNK, n);
-        for (uint64_t off = b0 + (uint64_t)wave * 65536u; off < b1; off += 4u * 65536u)
-            wave_copy_g2g(out + off, memcpy_src + off, (uint32_t)min((uint64_t)65536u, b1 - off), lane);
+        for (uint64_t off = b0 + (uint64_t)wave * 16384u; off < b1; off += (uint64_t)NW * 16384u)
+            wave_copy_g2g(out + off, memcpy_src + off, (uint32_t)min((uint64_t)16384u, b1 - off), lane);
         return;
     }
 
-    ChunkDesc d; d.lead = 0; d.enc_len = 0; d.last_end = 0; d.mcode0 = 0;
-    if ((uint32_t)t < cnt) d = desc[ck0 + t];
-    s_desc[t] = d;
-    const Agg mine = ((uint32_t)t < cnt) ? agg_of_chunk(d, (ck0 + t) * HB_CHUNK) : agg_identity();
-    s[t] = mine;
-    s_nf[t] = mine.has ? mine.F : 0xFFFFFFFFu;
+    if (t < 256) {
+        ChunkDesc d; d.lead = 0; d.enc_len = 0; d.last_end = 0; d.mcode0 = 0;
+        if ((uint32_t)t < cnt) d = desc[ck0 + t];
+        s_desc[t] = d;
+        const Agg mine = ((uint32_t)t < cnt) ? agg_of_chunk(d, (ck0 + t) * HB_CHUNK) : agg_identity();
+        s[t] = mine;
+        s_nf[t] = mine.has ? mine.F : 0xFFFFFFFFu;
+    }
     __syncthreads();
     block_scan_agg(s, t);                                             // inclusive prefix within the tile
     for (int dd = 1; dd < 256; dd <<= 1) {                            // inclusive suffix-min of F within the tile
-        const uint32_t x = s_nf[t], y = (t + dd < 256) ? s_nf[t + dd] : 0xFFFFFFFFu;
+        uint32_t x = 0, y = 0xFFFFFFFFu;
+        if (t < 256) { x = s_nf[t]; if (t + dd < 256) y = s_nf[t + dd]; }
         __syncthreads();
-        s_nf[t] = min(x, y);
+        if (t < 256) s_nf[t] = min(x, y);
         __syncthreads();
     }
     const Agg tpre = tile_pre[blockIdx.x];
@@ -367,7 +452,7 @@ __global__ __launch_bounds__(256) void k_stitch(const ChunkDesc *__restrict__ de
     if (index_base_ext) index = index_base_ext;
     else if (frame_base && plan->index_off) index = frame_base + plan->index_off;
 
-    for (uint32_t c = wave; c < cnt; c += 4) {
+    for (uint32_t c = wave; c < cnt; c += NW) {
         const uint32_t ck = ck0 + c;
         const ChunkDesc cd = s_desc[c];
         const uint32_t start = ck * HB_CHUNK;
@@ -377,21 +462,20 @@ __global__ __launch_bounds__(256) void k_stitch(const ChunkDesc *__restrict__ de
         if (NF == 0xFFFFFFFFu) NF = (uint32_t)n;                                  // ... or the end of the block
         const uint32_t a = P.has ? P.E : 0u;
         const uint64_t O = (uint64_t)agg_bytes(P);
-        const uint8_t *rec = records + (size_t)ck * HB_RSTRIDE;
         uint64_t I = O;
-        uint32_t a2 = a, tpos = start, roff = 0;
+        uint32_t a2 = a, tpos = start;
         if (cd.last_end) {
             const uint32_t tl = start + cd.lead - a;                  // literal run closed by this chunk's first match
             const uint32_t hdr = 1 + lz4_ext_bytes(tl);
             const uint32_t carry_lits = start - a;
             wave_write_lit_header(out + O, tl, cd.mcode0, lane);
-            wave_copy_g2g(out + O + hdr + carry_lits, rec, cd.enc_len, lane);
+            wave_copy_g2g(out + O + hdr + carry_lits, records + (size_t)ck * HB_RSTRIDE, cd.enc_len, lane);
             I = O + hdr + carry_lits + cd.enc_len;
-            a2 = start + cd.last_end; tpos = a2; roff = cd.enc_len;
+            a2 = start + cd.last_end; tpos = a2;
         }
-        // trailing literals: part of the run that ends at NF
+        // trailing literals (straight from the source): part of the run that ends at NF
         const uint32_t hdr2 = 1 + lz4_ext_bytes(NF - a2);
-        wave_copy_g2g(out + I + hdr2 + (tpos - a2), rec + roff, end - tpos, lane);
+        wave_copy_g2g(out + I + hdr2 + (tpos - a2), src + tpos, end - tpos, lane);
         if (ck + 1 == nchunks) wave_write_lit_header(out + I, NF - a2, 0, lane);  // final literal-only sequence
         if (index && lane == 0) {
             uint32_t *e = (uint32_t *)(index + HB_IDX_HDR_BYTES) + 4 * (size_t)ck;
@@ -442,9 +526,9 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
     hb_prof_end(s);
     if (L.nchunks) {
         hb_prof_begin("k_stitch", s);
-        hipLaunchKernelGGL(k_stitch, dim3(L.ntiles), dim3(256), 0, s, desc, records, tile_pre, tile_suf, plan, L.nchunks,
-                           (uint64_t)a.n, out, a.frame ? (uint8_t *)nullptr : a.index, a.frame ? a.dst : (uint8_t *)nullptr,
-                           a.memcpy_src);
+        hipLaunchKernelGGL(k_stitch, dim3(L.ntiles), dim3(STITCH_THREADS), 0, s, desc, records, a.src, tile_pre, tile_suf,
+                           plan, L.nchunks, (uint64_t)a.n, out, a.frame ? (uint8_t *)nullptr : a.index,
+                           a.frame ? a.dst : (uint8_t *)nullptr, a.memcpy_src);
         hb_prof_end(s);
     }
     HB_HIP_TRY(hipGetLastError());
