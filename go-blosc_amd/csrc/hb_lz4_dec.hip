@@ -59,7 +59,33 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
 __device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged, const uint8_t *g, uint32_t slen,
                                              uint32_t &si, uint32_t &acc, int lane) {
     uint64_t sum = acc;
-    for (;;) {
+    for (uint32_t round = 0;; round++) {
+        if (round == 1) {
+            // 64 bytes of 255 and counting: a literal run of MiB.  Scan 4 KiB per round trip with four 16-byte
+            // loads per lane in flight, straight from HBM/L2; the byte-granular loop below finishes the tail.
+            for (;;) {
+                bool allff = true;
+                u32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = si + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+                    if (i + 16u <= slen) v[k] = ld16u(g + i); else { v[k].x = 0; v[k].y = 0; v[k].z = 0; v[k].w = 0; }
+                }
+                uint32_t adv = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool ff = (v[k].x & v[k].y & v[k].z & v[k].w) == 0xFFFFFFFFu;
+                    const unsigned long long bad = __ballot(!ff);
+                    if (allff) {
+                        if (bad) { adv += 16u * (uint32_t)__builtin_ctzll(bad); allff = false; }
+                        else adv += 1024u;
+                    }
+                }
+                sum += 255ull * adv; si += adv;
+                if (sum > 0xFFFFFFF0ull) return false;
+                if (!allff) break;
+            }
+        }
         const uint32_t i = si + lane;
         uint32_t b = 0;                                   // out of range reads as a terminator
         if (i < slen) b = (i < staged) ? in[i] : g[i];
@@ -75,10 +101,47 @@ __device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged,
     }
 }
 
+#define DLITCAP 16u
+#define DMCAP 32u             // matches up to this long are copied by their own lane
+
+__device__ __forceinline__ uint32_t dec_read4(const uint8_t *base, uint32_t a) {     // unaligned 4-byte LDS read
+    const uint32_t *w = (const uint32_t *)base;
+    const uint32_t w0 = w[a >> 2], w1 = w[(a >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+}
+__device__ __forceinline__ uint32_t dec_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// copy a match inside the LDS image of the chunk; all arguments wave-uniform, source fully produced
+__device__ __forceinline__ void dec_match_copy(uint8_t *s_out, uint32_t md, uint32_t off, uint32_t ml, int lane) {
+    if (off >= 64u || off >= ml) {
+        for (uint32_t c0 = 0; c0 < ml; c0 += 64) {
+            const uint32_t i = c0 + lane;
+            uint8_t v = 0;
+            if (i < ml) v = s_out[md + i - off];
+            if (i < ml) s_out[md + i] = v;
+        }
+    } else {                                                   // overlapping: the source is [md-off, md), repeated
+        uint32_t m = (uint32_t)lane % off;
+        const uint32_t step = 64u % off;
+        for (uint32_t c0 = 0; c0 < ml; c0 += 64) {
+            const uint32_t i = c0 + lane;
+            if (i < ml) s_out[md + i] = s_out[md - off + m];
+            m += step; if (m >= off) m -= off;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
                                                     DecPlan *plan) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_MAX + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_MAX + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
     if (plan->mode != DEC_INDEXED) return;
     const int lane = threadIdx.x;
@@ -94,10 +157,22 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         bool ok = s0 <= s1 && s1 <= n_src && d0 <= d1 && d1 <= nbytes && (d1 - d0) <= DEC_OUT_MAX;
         if (u == 0) ok = ok && s0 == 0 && d0 == 0 && rem == HB_IDX_AT_TOKEN;
         if (last) ok = ok && s1 == n_src && d1 == nbytes;
+        if (rem != HB_IDX_AT_TOKEN && tokpos >= n_src) ok = false;
         if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
         const uint32_t slen = s1 - s0, outlen = d1 - d0;
-        // stage the head of the slice (all of it, normally)
         const uint8_t *g = src + s0;
+
+        // the whole unit lies inside one literal run (incompressible chunk): HBM -> HBM, no LDS
+        if (rem != HB_IDX_AT_TOKEN && rem >= outlen) {
+            const uint32_t left = rem - outlen;
+            bool fine = slen == outlen;
+            if (last) fine = fine && left == 0; else fine = fine && rem1 == left && tok1 == tokpos;
+            if (!fine) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
+            wave_copy_g2g(dst + d0, g, outlen, lane);
+            continue;
+        }
+
+        // stage the head of the slice (all of it, normally)
         const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
         const uint32_t staged = slen < DEC_IN_MAX - 16u ? slen : DEC_IN_MAX - 16u;
         {
@@ -106,61 +181,122 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_in)[i] = ga[i];
         }
         uint32_t tok = 0;
-        if (rem != HB_IDX_AT_TOKEN) { if (tokpos >= n_src) ok = false; else tok = src[tokpos]; }
+        if (rem != HB_IDX_AT_TOKEN) tok = src[tokpos];
         wave_sync();
         const uint8_t *in = s_in + sh;
         uint32_t si = 0, di = 0;
         bool at_token = false;       // state when the unit stops
-        bool need_token = (rem == HB_IDX_AT_TOKEN);
-        if (need_token) rem = 0;
-        while (ok) {
-            if (need_token) {
-                if (si >= slen) { ok = false; break; }
-                tokpos = s0 + si;
-                tok = (si < staged) ? in[si] : g[si];
-                si++;
-                rem = tok >> 4;
-                if (rem == 15u && !dec_read_ext(in, staged, g, slen, si, rem, lane)) { ok = false; break; }
-                need_token = false;
-            }
-            {   // literal phase
-                const uint32_t take = min(rem, outlen - di);
-                if (take > slen - si) { ok = false; break; }
-                if (si + take <= staged) { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = in[si + i]; }
-                else { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = g[si + i]; }
-                si += take; di += take; rem -= take;
-            }
-            if (rem > 0 || di == outlen) { at_token = false; break; }
-            {   // match phase
-                if (slen - si < 2) { ok = false; break; }         // also: block ends after literals -> serial decides
+        bool done = false;
+
+        // State machine.  slow != 0: handle ONE sequence of any shape (length extensions of any size, bytes
+        // outside the staged window, end of the unit inside a literal run); slow == 2 starts at a token,
+        // slow == 1 inside the literal run (rem, tok) the unit begins in.  slow == 0: the window parser below.
+        int slow = 1;
+        if (rem == HB_IDX_AT_TOKEN) { rem = 0; slow = 0; }
+        const uint32_t lim = staged;                            // the window parser only looks at staged bytes
+        while (ok && !done) {
+            if (slow) {
+                if (slow == 2) {
+                    if (si >= slen) { ok = false; break; }
+                    tokpos = s0 + si;
+                    tok = (si < staged) ? in[si] : g[si];
+                    si++;
+                    rem = tok >> 4;
+                    if (rem == 15u && !dec_read_ext(in, staged, g, slen, si, rem, lane)) { ok = false; break; }
+                }
+                slow = 0;
+                {   // literal phase
+                    const uint32_t take = min(rem, outlen - di);
+                    if (take > slen - si) { ok = false; break; }
+                    if (si + take <= staged) { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = in[si + i]; }
+                    else { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = g[si + i]; }
+                    si += take; di += take; rem -= take;
+                }
+                if (rem > 0 || di == outlen) { at_token = false; done = true; break; }
+                // match phase
+                if (slen - si < 2) { ok = false; break; }             // also: block ends after literals -> serial decides
                 const uint32_t b0 = (si < staged) ? in[si] : g[si], b1 = (si + 1 < staged) ? in[si + 1] : g[si + 1];
                 const uint32_t offset = b0 | (b1 << 8);
                 si += 2;
                 uint32_t mlen = (tok & 15u) + 4u;
                 if ((tok & 15u) == 15u && !dec_read_ext(in, staged, g, slen, si, mlen, lane)) { ok = false; break; }
                 if (offset == 0 || offset > di || mlen > outlen - di) { ok = false; break; }
-                wave_sync();                                       // earlier s_out writes visible
-                if (offset >= 64u) {
-                    for (uint32_t c0 = 0; c0 < mlen; c0 += 64) {
-                        const uint32_t i = c0 + lane;
-                        uint8_t v = 0;
-                        if (i < mlen) v = s_out[di + i - offset];
-                        if (i < mlen) s_out[di + i] = v;
-                        wave_sync();
-                    }
-                } else {
-                    uint32_t m = (uint32_t)lane % offset;          // source is always inside [di-offset, di)
-                    const uint32_t step = 64u % offset;
-                    for (uint32_t c0 = 0; c0 < mlen; c0 += 64) {
-                        const uint32_t i = c0 + lane;
-                        if (i < mlen) s_out[di + i] = s_out[di - offset + m];
-                        m += step; if (m >= offset) m -= offset;
-                    }
-                }
+                dec_match_copy(s_out, di, offset, mlen, lane);
                 di += mlen;
+                continue;
             }
-            if (si == slen || di == outlen) { at_token = true; break; }
-            need_token = true;
+            if (si == slen || di == outlen) { at_token = true; done = true; break; }
+            // ---- 64 stream bytes at once: every lane parses "as if a token started at my byte" ----
+            const uint32_t base = si, p = base + (uint32_t)lane;
+            const uint32_t w = dec_read4(s_in, sh + p);
+            const uint32_t t = w & 255u;
+            uint32_t lit = t >> 4, nbl = 0;
+            bool cplx = p >= lim;
+            if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
+            const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
+            if (offpos + 3u > lim) cplx = true;                  // literal-only tail, or too close to the edge
+            const uint32_t x = dec_read4(s_in, sh + (cplx ? 0u : offpos));
+            const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
+            uint32_t mlen = 4u + mn, nbm = 0;
+            if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
+            const uint32_t nxt = offpos + 2u + nbm;
+            // ---- follow the real token chain through the window (scalar: ballot / readlane only) ----
+            const unsigned long long cmask = __ballot(cplx);
+            unsigned long long tmask = 0;
+            uint32_t cur = si;
+            while (cur - base < 64u) {
+                const uint32_t j = cur - base;
+                if ((cmask >> j) & 1ull) break;
+                tmask |= 1ull << j;
+                cur = __builtin_amdgcn_readlane(nxt, (int)j);
+            }
+            bool istok = (tmask >> lane) & 1ull;
+            uint32_t olen = istok ? lit + mlen : 0u;
+            const uint32_t incl = dec_incl_scan(olen, lane);
+            const uint32_t dpos = di + incl - olen;
+            uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            const unsigned long long om = __ballot(istok && dpos + olen > outlen);
+            if (om) {                                            // this sequence passes the end of the unit: slow path
+                const int jx = __builtin_ctzll(om);
+                tmask &= (1ull << jx) - 1ull;
+                cur = base + (uint32_t)jx;
+                total = __builtin_amdgcn_readlane(dpos, jx) - di;
+                istok = istok && lane < jx;
+            }
+            if (tmask == 0) { slow = 2; continue; }
+            // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
+            if (__ballot(istok && (offv == 0u || offv > dpos + lit))) { ok = false; break; }
+            // ---- literals: short runs by their own lane, long runs by the whole wave ----
+            if (istok && lit <= DLITCAP) for (uint32_t k = 0; k < lit; k++) s_out[dpos + k] = in[lsrc + k];
+            unsigned long long lm = __ballot(istok && lit > DLITCAP);
+            while (lm) {
+                const int l = __builtin_ctzll(lm);
+                const uint32_t sp = __builtin_amdgcn_readlane(lsrc, l), dp = __builtin_amdgcn_readlane(dpos, l);
+                const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
+                for (uint32_t k = lane; k < ln; k += 64) s_out[dp + k] = in[sp + k];
+                lm &= lm - 1;
+            }
+            // ---- matches: every lane copies its own short match as soon as its source is final.  Everything
+            //      before the first pending match is final, so each round retires at least that one; matches
+            //      longer than DMCAP bytes are copied by the whole wave when they come first. ----
+            const uint32_t mdv = dpos + lit;                               // where my match goes
+            const uint32_t srcend = mdv - offv + (mlen < offv ? mlen : offv); // end of the part of the source that is not my own output
+            unsigned long long pend = tmask;
+            while (pend) {
+                const int f = __builtin_ctzll(pend);
+                const uint32_t X = __builtin_amdgcn_readlane(mdv, f);
+                const uint32_t mlf = __builtin_amdgcn_readlane(mlen, f);
+                if (mlf > DMCAP) {
+                    dec_match_copy(s_out, X, __builtin_amdgcn_readlane(offv, f), mlf, lane);
+                    pend &= pend - 1;
+                    continue;
+                }
+                const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP && srcend <= X;
+                if (ready) for (uint32_t k = 0; k < mlen; k++) s_out[mdv + k] = s_out[mdv - offv + k];
+                pend &= ~__ballot(ready);
+            }
+            di += total;
+            si = cur;
         }
         // end-state check against the next entry
         if (ok) {
@@ -181,17 +317,17 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             if (head == 0) { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + i * 16u) = *(const u32x4 *)(s_out + i * 16u); }
             else {
                 for (uint32_t i = lane; i < body; i += 64) {
-                    const uint8_t *p = s_out + head + i * 16u;
+                    const uint8_t *q = s_out + head + i * 16u;
                     u32x4 v;
-                    v.x = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-                    v.y = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
-                    v.z = (uint32_t)p[8] | ((uint32_t)p[9] << 8) | ((uint32_t)p[10] << 16) | ((uint32_t)p[11] << 24);
-                    v.w = (uint32_t)p[12] | ((uint32_t)p[13] << 8) | ((uint32_t)p[14] << 16) | ((uint32_t)p[15] << 24);
+                    v.x = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                    v.y = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+                    v.z = (uint32_t)q[8] | ((uint32_t)q[9] << 8) | ((uint32_t)q[10] << 16) | ((uint32_t)q[11] << 24);
+                    v.w = (uint32_t)q[12] | ((uint32_t)q[13] << 8) | ((uint32_t)q[14] << 16) | ((uint32_t)q[15] << 24);
                     *(u32x4 *)(o + head + i * 16u) = v;
                 }
             }
-            const uint32_t done = head + body * 16u;
-            if (done + lane < outlen) o[done + lane] = s_out[done + lane];
+            const uint32_t done_b = head + body * 16u;
+            if (done_b + lane < outlen) o[done_b + lane] = s_out[done_b + lane];
         }
         wave_sync();
     }

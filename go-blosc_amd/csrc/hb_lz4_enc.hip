@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
         const int mend_max = len - 5;                     // matches end at or before this
 
         // emit the queued sequences, one per lane
-        auto flush = [&]() {
+        auto flush = [&]() __attribute__((always_inline)) {
             const bool act = lane < nq;
             const uint32_t end = q_mp + q_ml;
             uint32_t prev = __shfl_up(end, 1);
