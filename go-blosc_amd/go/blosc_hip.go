@@ -1,0 +1,220 @@
+//go:build hip
+
+// blosc_hip.go — the cgo shim a go-blosc maintainer adds (build tag `hip`) to run the Shuffle/BitShuffle
+// filters and the LZ4 codec on an MI355X through libhipblosc.so (include/hipblosc.h).
+//
+// It plugs into the reference's own two seams and changes nothing else:
+//   * the codec plugin seam      codec.go:15-38   RegisterCodec(LZ4, hipLZ4{})
+//   * the filter hook seam       shuffle.go:26-57, :154-174 (hooks declared in shuffle_amd64.go:21-41,
+//                                stubs in shuffle_generic.go:15-52)  ->  the four xxxHIP functions below
+// plus an optional fused fast path (CompressHIP / DecompressHIP) that replaces compressBackend /
+// decompressBackend (blosc.go:320-434) in one device round trip.
+//
+// STATUS: written against the C ABI, NOT compiled — this image has no Go toolchain and the reference's
+// module dependencies are not vendored (SURVEY.md §0.9).  The same ABI is exercised from Python (ctypes)
+// by tests/ and bench.py.
+package blosc
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../lib -lhipblosc -Wl,-rpath,${SRCDIR}/../lib
+#include <stdlib.h>
+#include "hipblosc.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"unsafe"
+)
+
+// MinOffloadBytes: below this the PCIe round trip costs more than the pure-Go path (config 1 of
+// BASELINE.json, 100 KB, stays on the CPU).  Tunable by the caller.
+var MinOffloadBytes = 1 << 20
+
+// Device used by the host-pointer entry points.
+var Device = 0
+
+var useHIP bool
+
+func init() {
+	useHIP = C.hb_init() == C.HB_OK && C.hb_device_count() > 0
+	if useHIP {
+		RegisterCodec(LZ4, &hipLZ4{fallback: &lz4Codec{}}) // codec.go:36-38
+	}
+}
+
+// hbError maps a C-ABI code back to the reference's sentinels, keeping the bare-vs-wrapped distinction
+// (bare ErrInvalidData / ErrInvalidHeader: blosc.go:269-271, :297-299, :385-390; the rest wrapped with %w).
+func hbError(code C.int64_t) error {
+	switch code {
+	case C.HB_ERR_INVALID_DATA:
+		return ErrInvalidData
+	case C.HB_ERR_INVALID_HEADER:
+		return ErrInvalidHeader
+	case C.HB_ERR_INVALID_VERSION:
+		return fmt.Errorf("%w: (device path)", ErrInvalidVersion)
+	case C.HB_ERR_INVALID_CODEC:
+		return fmt.Errorf("%w: (device path)", ErrInvalidCodec)
+	case C.HB_ERR_SIZE_MISMATCH:
+		return fmt.Errorf("%w: (device path)", ErrSizeMismatch)
+	case C.HB_ERR_DATA_TOO_LARGE:
+		return ErrDataTooLarge
+	case C.HB_ERR_COMPRESSION_FAILED:
+		return fmt.Errorf("%w: hipblosc", ErrCompressionFailed)
+	case C.HB_ERR_DECOMPRESSION_FAILED:
+		return fmt.Errorf("%w: hipblosc", ErrDecompressionFailed)
+	default:
+		return fmt.Errorf("hipblosc: %s", C.GoString(C.hb_strerror(C.int(code))))
+	}
+}
+
+func ptr(b []byte) unsafe.Pointer {
+	if len(b) == 0 {
+		return nil
+	}
+	return unsafe.Pointer(&b[0]) // Go memory is only borrowed for the duration of the call (cgo rule)
+}
+
+// ---------------------------------------------------------------------------------------------
+// codec plugin: CodecInterface (codec.go:15-24) for blosc.LZ4
+// ---------------------------------------------------------------------------------------------
+type hipLZ4 struct{ fallback CodecInterface }
+
+func (c *hipLZ4) Name() string { return "lz4" } // codec.go:61
+
+// Compress: codec.go:63-75.  `level` is ignored, exactly as the reference's LZ4 codec ignores it.
+func (c *hipLZ4) Compress(data []byte, level int) ([]byte, error) {
+	if !useHIP || len(data) < MinOffloadBytes {
+		return c.fallback.Compress(data, level)
+	}
+	buf := make([]byte, int(C.hb_lz4_bound(C.size_t(len(data))))) // codec.go:65
+	n := C.hb_lz4_compress(ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)), C.int(Device))
+	if n < 0 {
+		return nil, fmt.Errorf("lz4 compress: %w", hbError(n)) // codec.go:67-69
+	}
+	return buf[:n], nil
+}
+
+// Decompress: codec.go:77-84; returns buf[:n] and lets the frame layer detect a size mismatch.
+func (c *hipLZ4) Decompress(data []byte, expectedSize int) ([]byte, error) {
+	if !useHIP || expectedSize < MinOffloadBytes {
+		return c.fallback.Decompress(data, expectedSize)
+	}
+	buf := make([]byte, expectedSize)
+	n := C.hb_lz4_decompress(ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)), C.int(Device))
+	if n < 0 {
+		return nil, fmt.Errorf("lz4 decompress: %w", hbError(n))
+	}
+	return buf[:n], nil
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter hooks: same contract as shuffleBytesAVX2 & co. (shuffle_amd64.go:21-41): dst is pre-allocated with
+// len(dst) == len(src); return true = handled.  hb_filter implements the COMPLETE semantics including
+// leftover elements and tail bytes, so the scalar finisher of shuffle.go:42-55 / :162-173 has nothing left
+// to do; the call sites test `useHIP && n >= MinOffloadBytes` next to `useAVX2` / `useNEON`.
+// ---------------------------------------------------------------------------------------------
+func filterHIP(op C.int, dst, src []byte, typeSize int) bool {
+	if !useHIP || len(src) < MinOffloadBytes || len(dst) != len(src) {
+		return false
+	}
+	return C.hb_filter(op, ptr(dst), ptr(src), C.size_t(len(src)), C.int(typeSize), C.int(Device)) == C.HB_OK
+}
+
+func shuffleBytesHIP(dst, src []byte, typeSize int) bool   { return filterHIP(C.HB_OP_SHUFFLE, dst, src, typeSize) }
+func unshuffleBytesHIP(dst, src []byte, typeSize int) bool { return filterHIP(C.HB_OP_UNSHUFFLE, dst, src, typeSize) }
+func bitShuffleHIP(dst, src []byte, typeSize int) bool     { return filterHIP(C.HB_OP_BITSHUFFLE, dst, src, typeSize) }
+func bitUnshuffleHIP(dst, src []byte, typeSize int) bool   { return filterHIP(C.HB_OP_BITUNSHUFFLE, dst, src, typeSize) }
+
+// ---------------------------------------------------------------------------------------------
+// fused frame path: one H2D, filter + LZ4 + header on the device, one D2H.  Drop-in for
+// compressBackend / decompressBackend (blosc.go:320-374, :377-434) when opts.Codec == LZ4.
+// ---------------------------------------------------------------------------------------------
+
+// CompressHIP has CompressWithOptions' semantics (blosc.go:268-286).  withIndex appends the restart index
+// after NBytesComp (ignored by every go-blosc decoder, blosc.go:385-393) so DecompressHIP can decode the
+// frame chunk-parallel; the returned slice is then longer than NBytesComp.
+func CompressHIP(data []byte, opts Options, withIndex bool) ([]byte, error) {
+	if len(data) == 0 {
+		return nil, ErrInvalidData // blosc.go:269-271
+	}
+	if !useHIP || opts.Codec != LZ4 || len(data) < MinOffloadBytes {
+		return CompressWithOptions(data, opts)
+	}
+	var o C.uint
+	if withIndex {
+		o |= C.HB_OPT_INDEX_TRAILER
+	}
+	buf := make([]byte, int(C.hb_frame_bound(C.size_t(len(data)))))
+	n := C.hb_compress_frame(ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)),
+		C.int(opts.Codec), C.int(opts.Level), C.int(opts.Shuffle), C.int(opts.TypeSize), o, C.int(Device))
+	if n < 0 {
+		return nil, hbError(n)
+	}
+	return buf[:n], nil
+}
+
+// DecompressHIP has DecompressWithSize's semantics (blosc.go:296-303).
+func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
+	if len(data) < HeaderSize {
+		return nil, ErrInvalidHeader // blosc.go:297-299
+	}
+	h, err := ParseHeader(data)
+	if err != nil {
+		return nil, err
+	}
+	if !useHIP || int(h.NBytesOrig) < MinOffloadBytes || (!h.IsMemcpy() && Codec(h.VersionLZ) != LZ4 && Codec(h.VersionLZ) != LZ4HC) {
+		return DecompressWithSize(data, typeSize)
+	}
+	buf := make([]byte, int(h.NBytesOrig))
+	n := C.hb_decompress_frame(ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)), C.int(typeSize), C.int(Device))
+	if n < 0 {
+		return nil, hbError(n)
+	}
+	return buf[:n], nil
+}
+
+// CompressFramesHIP: independent frames, frame k on device k mod hb_device_count() (no collective;
+// SURVEY.md §8e).  Used for inputs >= 4 GiB, which the uint32 header cannot hold in one frame.
+func CompressFramesHIP(frames [][]byte, opts Options, withIndex bool) ([][]byte, []error) {
+	n := len(frames)
+	out := make([][]byte, n)
+	errs := make([]error, n)
+	if n == 0 {
+		return out, errs
+	}
+	srcs := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	dsts := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	defer C.free(unsafe.Pointer(&srcs[0]))
+	defer C.free(unsafe.Pointer(&dsts[0]))
+	lens := make([]C.size_t, n)
+	caps := make([]C.size_t, n)
+	rcs := make([]C.int64_t, n)
+	pin := make([]unsafe.Pointer, 0, 2*n) // C-allocated staging: Go pointers may not be stored in C memory
+	for k, f := range frames {
+		lens[k] = C.size_t(len(f))
+		caps[k] = C.hb_frame_bound(lens[k])
+		srcs[k] = C.hb_host_alloc(lens[k])
+		dsts[k] = C.hb_host_alloc(caps[k])
+		pin = append(pin, srcs[k], dsts[k])
+		copy(unsafe.Slice((*byte)(srcs[k]), len(f)), f)
+	}
+	var o C.uint
+	if withIndex {
+		o |= C.HB_OPT_INDEX_TRAILER
+	}
+	C.hb_compress_frames_multi(C.int(n), &srcs[0], &lens[0], &dsts[0], &caps[0], &rcs[0],
+		C.int(opts.Codec), C.int(opts.Level), C.int(opts.Shuffle), C.int(opts.TypeSize), o)
+	for k := range frames {
+		if rcs[k] < 0 {
+			errs[k] = hbError(rcs[k])
+		} else {
+			out[k] = append([]byte(nil), unsafe.Slice((*byte)(dsts[k]), int(rcs[k]))...)
+		}
+	}
+	for _, p := range pin {
+		C.hb_host_free(p)
+	}
+	return out, errs
+}
