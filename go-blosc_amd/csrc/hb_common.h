@@ -13,6 +13,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(1))) hb_u128u { u32x4 v; };
 struct __attribute__((packed, aligned(1))) hb_u64u { uint64_t v; };
 struct __attribute__((packed, aligned(1))) hb_u32u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) hb_u16u { uint16_t v; };
 
 __device__ __forceinline__ u32x4 ld16u(const uint8_t *p) { return ((const hb_u128u *)p)->v; }
 __device__ __forceinline__ void st16u(uint8_t *p, u32x4 v) { ((hb_u128u *)p)->v = v; }

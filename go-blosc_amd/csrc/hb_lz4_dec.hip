@@ -104,10 +104,30 @@ __device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged,
 #define DLITCAP 16u
 #define DMCAP 32u             // matches up to this long are copied by their own lane
 
-__device__ __forceinline__ uint32_t dec_read4(const uint8_t *base, uint32_t a) {     // unaligned 4-byte LDS read
-    const uint32_t *w = (const uint32_t *)base;
-    const uint32_t w0 = w[a >> 2], w1 = w[(a >> 2) + 1];
-    return __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+// gfx950 LDS takes unaligned ds_read/ds_write_b16/b32/b64 (hipcc emits them for align-1 types)
+__device__ __forceinline__ uint32_t dec_read4(const uint8_t *base, uint32_t a) { return ((const hb_u32u *)(base + a))->v; }
+
+// exact-length copy inside LDS, no overlap between [d, d+len) and [s, s+len): 8/4/2/1-byte pieces
+__device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uint32_t len) {
+    uint32_t k = 0;
+    for (; k + 8u <= len; k += 8u) ((hb_u64u *)(d + k))->v = ((const hb_u64u *)(s + k))->v;
+    if (len & 4u) { ((hb_u32u *)(d + k))->v = ((const hb_u32u *)(s + k))->v; k += 4u; }
+    if (len & 2u) { ((hb_u16u *)(d + k))->v = ((const hb_u16u *)(s + k))->v; k += 2u; }
+    if (len & 1u) d[k] = s[k];
+}
+// a match copied by one lane: out[md + k] = out[md - off + k]; pieces never read bytes they have not written yet
+__device__ __forceinline__ void lds_match_lane(uint8_t *out, uint32_t md, uint32_t off, uint32_t len) {
+    if (off >= 8u) { lds_copy_exact(out + md, out + md - off, len); return; }
+    if (off == 1u) {                                            // run of one byte
+        const uint64_t pat = 0x0101010101010101ull * out[md - 1u];
+        uint32_t k = 0;
+        for (; k + 8u <= len; k += 8u) ((hb_u64u *)(out + md + k))->v = pat;
+        if (len & 4u) { ((hb_u32u *)(out + md + k))->v = (uint32_t)pat; k += 4u; }
+        if (len & 2u) { ((hb_u16u *)(out + md + k))->v = (uint16_t)pat; k += 2u; }
+        if (len & 1u) out[md + k] = (uint8_t)pat;
+        return;
+    }
+    for (uint32_t k = 0; k < len; k++) out[md + k] = out[md - off + k];   // offsets 2..7: byte by byte
 }
 __device__ __forceinline__ uint32_t dec_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
             if (__ballot(istok && (offv == 0u || offv > dpos + lit))) { ok = false; break; }
             // ---- literals: short runs by their own lane, long runs by the whole wave ----
-            if (istok && lit <= DLITCAP) for (uint32_t k = 0; k < lit; k++) s_out[dpos + k] = in[lsrc + k];
+            if (istok && lit <= DLITCAP) lds_copy_exact(s_out + dpos, in + lsrc, lit);
             unsigned long long lm = __ballot(istok && lit > DLITCAP);
             while (lm) {
                 const int l = __builtin_ctzll(lm);
@@ -291,8 +311,9 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                     pend &= pend - 1;
                     continue;
                 }
-                const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP && srcend <= X;
-                if (ready) for (uint32_t k = 0; k < mlen; k++) s_out[mdv + k] = s_out[mdv - offv + k];
+                // ready: the source ends before the first pending match, or lies inside my own literals
+                const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP && (srcend <= X || offv <= lit);
+                if (ready) lds_match_lane(s_out, mdv, offv, mlen);
                 pend &= ~__ballot(ready);
             }
             di += total;
