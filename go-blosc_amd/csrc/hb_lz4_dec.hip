@@ -104,8 +104,14 @@ __device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged,
 #define DLITCAP 16u
 #define DMCAP 32u             // matches up to this long are copied by their own lane
 
-// gfx950 LDS takes unaligned ds_read/ds_write_b16/b32/b64 (hipcc emits them for align-1 types)
-__device__ __forceinline__ uint32_t dec_read4(const uint8_t *base, uint32_t a) { return ((const hb_u32u *)(base + a))->v; }
+// 4 bytes at any byte address of a 4-byte aligned LDS array: two aligned dwords + v_alignbyte.
+// gfx950 LDS also takes misaligned ds_read/ds_write_b16/b32/b64 (hipcc emits them for align-1 types) but
+// replays them; they still beat byte loops for the short exact-length copies below.
+__device__ __forceinline__ uint32_t dec_read4(const uint8_t *base, uint32_t a) {
+    const uint32_t *w = (const uint32_t *)base;
+    const uint32_t w0 = w[a >> 2], w1 = w[(a >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+}
 
 // exact-length copy inside LDS, no overlap between [d, d+len) and [s, s+len): 8/4/2/1-byte pieces
 __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uint32_t len) {

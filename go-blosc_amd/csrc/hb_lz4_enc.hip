@@ -110,10 +110,21 @@ size_t hb_lz4_index_bound(size_t n) {
 // ----------------------------------------------------------------------------------------------
 // k_match
 // ----------------------------------------------------------------------------------------------
+// 4 bytes at any byte address of an LDS array whose base is 4-byte aligned: two aligned dwords + v_alignbyte.
+// (gfx950 accepts a misaligned ds_read_b32, but replays it: measured 35 % slower for this kernel.)
 __device__ __forceinline__ uint32_t lds_read4(const uint8_t *base, uint32_t a) {
     const uint32_t *w = (const uint32_t *)base;
     const uint32_t w0 = w[a >> 2], w1 = w[(a >> 2) + 1];
     return __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+}
+
+// exact-length LDS -> LDS copy in 8/4/2/1-byte pieces (ranges do not overlap)
+__device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uint32_t len) {
+    uint32_t k = 0;
+    for (; k + 8u <= len; k += 8u) ((hb_u64u *)(d + k))->v = ((const hb_u64u *)(s + k))->v;
+    if (len & 4u) { ((hb_u32u *)(d + k))->v = ((const hb_u32u *)(s + k))->v; k += 4u; }
+    if (len & 2u) { ((hb_u16u *)(d + k))->v = ((const hb_u16u *)(s + k))->v; k += 2u; }
+    if (len & 1u) d[k] = s[k];
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -125,12 +136,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
+#define QCAP 128            // sequence queue slots (flushed 64 at a time)
+
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
                                               uint32_t nchunks) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
+    __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];     // {match pos | match len << 16, offset}
     const int lane = threadIdx.x;
 
     for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
@@ -149,14 +163,18 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
         wave_sync();
 
         int pos = 0, anchor = 0, o = 0, nq = 0, nseq = 0, miss = 0;
-        uint32_t q_mp = 0, q_ml = 0, q_off = 0;          // lane i: i-th queued sequence
         uint32_t batch_anchor = 0, lead = 0, mcode0 = 0;
         const int mstart_max = len - 12;                  // last position a match may start at
         const int mend_max = len - 5;                     // matches end at or before this
+        const uint8_t *data = s_data + sh;
+#define RD4(x) lds_read4(s_data, sh + (uint32_t)(x))
 
-        // emit the queued sequences, one per lane
+        // emit the first min(nq, 64) queued sequences, one per lane
         auto flush = [&]() __attribute__((always_inline)) {
-            const bool act = lane < nq;
+            const int cntb = nq < 64 ? nq : 64;
+            const bool act = lane < cntb;
+            const uint2 e = s_q[lane];
+            const uint32_t q_mp = e.x & 0xFFFFu, q_ml = e.x >> 16, q_off = e.y;
             const uint32_t end = q_mp + q_ml;
             uint32_t prev = __shfl_up(end, 1);
             if (lane == 0) prev = batch_anchor;
@@ -176,9 +194,9 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                     }
                 }
                 litdst = q;
-                if (lit <= LITCAP) for (uint32_t k = 0; k < lit; k++) s_out[q + k] = s_data[sh + prev + k];
+                if (lit <= LITCAP) lds_copy_exact(s_out + q, data + prev, lit);
                 q += lit;
-                s_out[q] = (uint8_t)q_off; s_out[q + 1] = (uint8_t)(q_off >> 8);
+                ((hb_u16u *)(s_out + q))->v = (uint16_t)q_off;
                 q += 2;
                 if (nbm) {
                     for (uint32_t k = 0; k + 1 < nbm; k++) s_out[q++] = 255;
@@ -190,7 +208,10 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 const int l = __builtin_ctzll(lm);
                 const uint32_t s = __builtin_amdgcn_readlane(prev, l), dq = __builtin_amdgcn_readlane(litdst, l);
                 const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
-                for (uint32_t k = lane; k < ln; k += 64) s_out[dq + k] = s_data[sh + s + k];
+                for (uint32_t k = lane * 4u; k < ln; k += 256u) {
+                    if (k + 4u <= ln) ((hb_u32u *)(s_out + dq + k))->v = ((const hb_u32u *)(data + s + k))->v;
+                    else for (uint32_t r = k; r < ln; r++) s_out[dq + r] = data[s + r];
+                }
                 lm &= lm - 1;
             }
             if (nseq == 0) {
@@ -199,23 +220,23 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 mcode0 = m0 < 15u ? m0 : 15u;
             }
             o += (int)__builtin_amdgcn_readlane(incl, 63);
-            batch_anchor = __builtin_amdgcn_readlane(end, nq - 1);
-            nseq += nq;
-            nq = 0;
+            batch_anchor = __builtin_amdgcn_readlane(end, cntb - 1);
+            nseq += cntb;
+            // keep what is queued beyond the 64 just emitted
+            const uint2 rest = s_q[64 + lane];
+            nq -= cntb;
+            if (lane < nq) s_q[lane] = rest;
         };
 
         while (pos <= mstart_max) {
             const int p = pos + lane;
-            const uint32_t a = sh + (uint32_t)p;
-            const uint32_t v = lds_read4(s_data, a);
-            const uint32_t vprev = lds_read4(s_data, a ? a - 1 : 0);
+            const uint32_t v = RD4(p);
             const bool valid = p <= mstart_max;
-            const bool rle = valid && p >= 1 && vprev == v;          // inside a run of equal 4-grams
+            const bool rle = valid && p >= 1 && RD4(p >= 1 ? p - 1 : 0) == v;   // inside a run of equal 4-grams
             const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
             uint32_t cand = s_tab[h];
             if (valid && !rle) s_tab[h] = (uint16_t)p;
-            const uint32_t cv = lds_read4(s_data, sh + cand);
-            const bool hit = valid && (int)cand < p && cv == v;
+            const bool hit = valid && (int)cand < p && RD4(cand) == v;
             if (!hit && rle) cand = (uint32_t)p - 1u;
             const bool ism = hit || rle;
             unsigned long long mask = __ballot(ism);
@@ -224,10 +245,10 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 uint32_t ml = 4;
                 bool lng = false;
                 if (ism) {
-                    const uint32_t x = lds_read4(s_data, a + 4) ^ lds_read4(s_data, sh + cand + 4);
+                    const uint32_t x = RD4(p + 4) ^ RD4(cand + 4);
                     if (x) ml = 4u + ((uint32_t)__builtin_ctz(x) >> 3);
                     else {
-                        const uint32_t y = lds_read4(s_data, a + 8) ^ lds_read4(s_data, sh + cand + 8);
+                        const uint32_t y = RD4(p + 8) ^ RD4(cand + 8);
                         if (y) ml = 8u + ((uint32_t)__builtin_ctz(y) >> 3);
                         else { ml = 12; lng = true; }
                     }
@@ -235,37 +256,46 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                     if (ml >= maxl) { ml = maxl; lng = false; }
                 }
                 const unsigned long long lmask = __ballot(lng);
+                // greedy left-to-right selection: scalar walk over the hit mask
+                unsigned long long sel = 0;
+                int last_end = anchor;
                 while (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    const int mp = pos + l;
-                    const int mc = (int)__builtin_amdgcn_readlane(cand, l);
-                    int mlen = (int)__builtin_amdgcn_readlane(ml, l);
-                    if ((lmask >> l) & 1ull) {             // still matching after 12 bytes: 256 bytes per step
+                    const int j = __builtin_ctzll(mask);
+                    int mlj = (int)__builtin_amdgcn_readlane(ml, j);
+                    if ((lmask >> j) & 1ull) {             // still matching after 12 bytes: 256 bytes per step
+                        const int mp = pos + j, mc = (int)__builtin_amdgcn_readlane(cand, j);
                         const int maxl = mend_max - mp;
                         for (;;) {
-                            const int i = mlen + 4 * lane;
+                            const int i = mlj + 4 * lane;
                             const int ic = i < maxl ? i : maxl;        // keep the reads inside the chunk image
-                            const uint32_t x = lds_read4(s_data, sh + (uint32_t)(mp + ic)) ^ lds_read4(s_data, sh + (uint32_t)(mc + ic));
+                            const uint32_t x = RD4(mp + ic) ^ RD4(mc + ic);
                             int eq = x ? (__builtin_ctz(x) >> 3) : 4;
                             const int avail = maxl - i;
                             if (avail < eq) eq = avail > 0 ? avail : 0;
-                            const bool full = (eq == 4);
-                            const unsigned long long part = __ballot(!full);
+                            const unsigned long long part = __ballot(eq != 4);
                             if (part) {
                                 const int f = __builtin_ctzll(part);
-                                mlen += 4 * f + (int)__builtin_amdgcn_readlane((uint32_t)eq, f);
+                                mlj += 4 * f + (int)__builtin_amdgcn_readlane((uint32_t)eq, f);
                                 break;
                             }
-                            mlen += 256;
+                            mlj += 256;
                         }
+                        if (lane == j) ml = (uint32_t)mlj;
                     }
-                    if (lane == nq) { q_mp = (uint32_t)mp; q_ml = (uint32_t)mlen; q_off = (uint32_t)(mp - mc); }
-                    nq++;
-                    anchor = mp + mlen;
-                    if (nq == 64) flush();
-                    const int rel = anchor - pos;
-                    mask = rel >= 64 ? 0ull : (mask & (~0ull << rel));
+                    sel |= 1ull << j;
+                    const int e = j + mlj;
+                    last_end = pos + e;
+                    mask = e >= 64 ? 0ull : (mask & (~0ull << e));
                 }
+                // queue the selected matches, compacted in position order
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
+                if ((sel >> lane) & 1ull) {
+                    uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = (uint32_t)p - cand;
+                    s_q[nq + rank] = e;
+                }
+                nq += __builtin_popcountll(sel);
+                anchor = last_end;
+                if (nq >= 64) flush();
                 miss = 0;
             } else {
                 miss++;
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
             const int nxt = pos + 64 + ((miss >> 2) << 6);
             pos = anchor > nxt ? anchor : nxt;
         }
-        if (nq) flush();
+        while (nq > 0) flush();
         wave_sync();
         uint8_t *rec = records + (size_t)ck * HB_RSTRIDE;
         for (int i = lane * 16; i < o; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_out + i);
