@@ -269,12 +269,18 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             // ---- follow the real token chain through the window (scalar: ballot / readlane only) ----
             const unsigned long long cmask = __ballot(cplx);
             unsigned long long tmask = 0;
-            uint32_t cur = si;
-            while (cur - base < 64u) {
-                const uint32_t j = cur - base;
-                if ((cmask >> j) & 1ull) break;
-                tmask |= 1ull << j;
-                cur = __builtin_amdgcn_readlane(nxt, (int)j);
+            uint32_t cur;
+            {
+                // one bit-set + one readlane per token; a "complex" lane ends the walk (its successor is >= 64)
+                const uint32_t nrel = cplx ? 64u : nxt - base;
+                uint32_t j = 0;
+                do {
+                    asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                    j = __builtin_amdgcn_readlane(nrel, (int)j);
+                } while (j < 64u);
+                cur = base + j;
+                const unsigned long long cm = tmask & cmask;     // at most the last visited lane
+                if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); }
             }
             bool istok = (tmask >> lane) & 1ull;
             uint32_t olen = istok ? lit + mlen : 0u;

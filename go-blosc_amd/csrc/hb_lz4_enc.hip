@@ -259,6 +259,25 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 // greedy left-to-right selection: scalar walk over the hit mask
                 unsigned long long sel = 0;
                 int last_end = anchor;
+                if (lmask == 0) {
+                    // all lengths known: every hit lane computes its successor (first hit at or after the end of
+                    // its match, 64 = leaves the step) and the walk is one bit-set + one readlane per sequence
+                    const uint32_t x = (uint32_t)lane + ml;
+                    uint32_t succ = 64;
+                    if (x < 64u) {
+                        const unsigned long long m = mask >> x;
+                        if (m) succ = x + (uint32_t)__builtin_ctzll(m);
+                    }
+                    uint32_t j = (uint32_t)__builtin_ctzll(mask);
+                    uint32_t lastj = j;
+                    do {
+                        asm volatile("s_bitset1_b64 %0, %1" : "+s"(sel) : "s"(j));
+                        lastj = j;
+                        j = __builtin_amdgcn_readlane(succ, (int)j);
+                    } while (j < 64u);
+                    last_end = pos + (int)lastj + (int)__builtin_amdgcn_readlane(ml, (int)lastj);
+                    mask = 0;
+                }
                 while (mask) {
                     const int j = __builtin_ctzll(mask);
                     int mlj = (int)__builtin_amdgcn_readlane(ml, j);
