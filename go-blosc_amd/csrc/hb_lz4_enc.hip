@@ -230,31 +230,42 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 
         while (pos <= mstart_max) {
             const int p = pos + lane;
-            const uint32_t v = RD4(p);
+            // ---- 12 bytes at my position: 4 aligned dwords + v_alignbyte (one LDS round trip) ----
+            const uint32_t ap = sh + (uint32_t)p;
+            const uint32_t *wp = (const uint32_t *)s_data + (ap >> 2);
+            const uint32_t p0 = wp[0], p1 = wp[1], p2 = wp[2], p3 = wp[3];
+            const uint32_t prevb = s_data[sh + (uint32_t)(pos > 0 ? pos - 1 : 0)];   // wave-uniform: byte before lane 0
+            const uint32_t v = __builtin_amdgcn_alignbyte(p1, p0, ap & 3u);
+            const uint32_t v4 = __builtin_amdgcn_alignbyte(p2, p1, ap & 3u);
+            const uint32_t v8 = __builtin_amdgcn_alignbyte(p3, p2, ap & 3u);
             const bool valid = p <= mstart_max;
-            const bool rle = valid && p >= 1 && RD4(p >= 1 ? p - 1 : 0) == v;   // inside a run of equal 4-grams
+            // inside a run of equal 4-grams <=> data[p-1] == data[p] == ... == data[p+3]
+            uint32_t before = (uint32_t)__shfl_up((int)(v & 255u), 1);
+            if (lane == 0) before = prevb;
+            const uint32_t b4 = (v & 255u) * 0x01010101u;
+            const bool rle = valid && p >= 1 && v == b4 && before == (v & 255u);
             const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
             uint32_t cand = s_tab[h];
             if (valid && !rle) s_tab[h] = (uint16_t)p;
-            const bool hit = valid && (int)cand < p && RD4(cand) == v;
-            if (!hit && rle) cand = (uint32_t)p - 1u;
+            // ---- 12 bytes at the candidate (second round trip) ----
+            const uint32_t ac = sh + cand;
+            const uint32_t *wc = (const uint32_t *)s_data + (ac >> 2);
+            const uint32_t c0 = wc[0], c1 = wc[1], c2 = wc[2], c3 = wc[3];
+            const uint32_t cv = __builtin_amdgcn_alignbyte(c1, c0, ac & 3u);
+            const uint32_t cv4 = __builtin_amdgcn_alignbyte(c2, c1, ac & 3u);
+            const uint32_t cv8 = __builtin_amdgcn_alignbyte(c3, c2, ac & 3u);
+            const bool hit = valid && (int)cand < p && cv == v;
             const bool ism = hit || rle;
+            // the offset-1 candidate of a run needs no second read: its match is the rest of the run
+            const uint32_t xa = hit ? (cv4 ^ v4) : (b4 ^ v4), xb = hit ? (cv8 ^ v8) : (b4 ^ v8);
+            cand = hit ? cand : (uint32_t)p - 1u;
             unsigned long long mask = __ballot(ism);
             if (mask) {
-                // every lane extends its own match to at most 12 bytes
-                uint32_t ml = 4;
-                bool lng = false;
-                if (ism) {
-                    const uint32_t x = RD4(p + 4) ^ RD4(cand + 4);
-                    if (x) ml = 4u + ((uint32_t)__builtin_ctz(x) >> 3);
-                    else {
-                        const uint32_t y = RD4(p + 8) ^ RD4(cand + 8);
-                        if (y) ml = 8u + ((uint32_t)__builtin_ctz(y) >> 3);
-                        else { ml = 12; lng = true; }
-                    }
-                    const uint32_t maxl = (uint32_t)(mend_max - p);
-                    if (ml >= maxl) { ml = maxl; lng = false; }
-                }
+                // every lane extends its own match to at most 12 bytes (branch-free)
+                uint32_t ml = xa ? 4u + ((uint32_t)__builtin_ctz(xa) >> 3) : (xb ? 8u + ((uint32_t)__builtin_ctz(xb) >> 3) : 12u);
+                bool lng = ism && (xa | xb) == 0u;
+                const uint32_t maxl = (uint32_t)(mend_max - p);
+                if (ml >= maxl) { ml = maxl; lng = false; }
                 const unsigned long long lmask = __ballot(lng);
                 // greedy left-to-right selection: scalar walk over the hit mask
                 unsigned long long sel = 0;
