@@ -314,8 +314,11 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
     uint8_t *filtered = work;                                         // first n bytes (256-aligned size)
     uint8_t *enc_work = work + ((n + 255) & ~(size_t)255) + 256;
     const bool filt = (shuffle == HB_SHUFFLE || shuffle == HB_BITSHUFFLE) && typesize > 1;   // blosc.go:329-333
+    // byte shuffle with typesize 2/4/8 on whole blocks of HB_CHUNK elements is fused into the matcher
+    const bool fused = filt && shuffle == HB_SHUFFLE && (typesize == 2 || typesize == 4 || typesize == 8) &&
+                       n % ((size_t)typesize * HB_CHUNK) == 0 && !(opts & HB_OPT_NO_FUSION);
     const uint8_t *in = (const uint8_t *)d_src;
-    if (filt) {
+    if (filt && !fused) {
         int rc = hb_launch_filter(shuffle == HB_SHUFFLE ? HB_OP_SHUFFLE : HB_OP_BITSHUFFLE, filtered,
                                   (const uint8_t *)d_src, n, typesize, s);
         if (rc) return rc;
@@ -325,7 +328,9 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
     a.src = in; a.n = n; a.dst = (uint8_t *)d_frame; a.cap = cap; a.index = nullptr;
     a.work = enc_work; a.result = d_result;
     a.frame = 1; a.codec = codec; a.shuffle = shuffle; a.typesize = typesize; a.opts = opts;
-    a.memcpy_src = (opts & HB_OPT_REFERENCE_MEMCPY) ? (const uint8_t *)d_src : in;   // blosc.go:343-345 vs Appendix D
+    a.fused_ts = fused ? typesize : 0;
+    // what a memcpy frame stores: blosc.go:343-345 (raw input) vs the round-trip-safe filtered bytes
+    a.memcpy_src = (opts & HB_OPT_REFERENCE_MEMCPY) ? (const uint8_t *)d_src : (fused ? nullptr : in);
     return hb_launch_lz4_encode(a, s);
 }
 

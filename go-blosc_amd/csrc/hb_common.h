@@ -65,3 +65,5 @@ void hb_prof_end(hipStream_t s);
 
 // ---- internal launch API shared between translation units ----
 int hb_launch_filter(int op, uint8_t *d_dst, const uint8_t *d_src, size_t n, int typesize, hipStream_t s);
+// same, but every kernel returns immediately unless *gate != 0 (gate is read on the device)
+int hb_launch_filter_gated(int op, uint8_t *d_dst, const uint8_t *d_src, size_t n, int typesize, const uint32_t *gate, hipStream_t s);

@@ -20,8 +20,9 @@
 // ----------------------------------------------------------------------------------------------
 template <int TS>
 __global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                     uint64_t ne, uint64_t ntiles) {
+                                                     uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
     __shared__ __attribute__((aligned(16))) uint32_t slab[4][TS][256];
+    if (gate && *gate == 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t(*my)[256] = slab[wave];
     for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, 
 
 template <int TS>
 __global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                       uint64_t ne, uint64_t ntiles) {
+                                                       uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
     __shared__ __attribute__((aligned(16))) uint32_t slab[4][TS][256];
+    if (gate && *gate == 0) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t(*my)[256] = slab[wave];
     for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
@@ -118,7 +120,8 @@ __global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
                                                          uint64_t n, uint64_t ne, uint32_t ts,
-                                                         uint64_t e_begin, int inverse) {
+                                                         uint64_t e_begin, int inverse, const uint32_t *gate) {
+    if (gate && *gate == 0) return;
     const uint64_t cnt = ne - e_begin, total = cnt * ts, tail0 = ne * ts;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -140,7 +143,8 @@ __global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ d
 // typesize 4: one lane owns one group of 8 elements = one 32-byte window (in and out).
 template <bool INVERSE>
 __global__ __launch_bounds__(256) void k_bitshuffle4(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                     uint64_t ngroups) {
+                                                     uint64_t ngroups, const uint32_t *gate) {
+    if (gate && *gate == 0) return;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
         const u32x4 a = ld16u(src + g * 32), b = ld16u(src + g * 32 + 16);
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(256) void k_bitshuffle4(uint8_t *__restrict__ dst, 
 // any typesize: one thread per (group, byte position).  shuffle.go:184-200 / :261-277
 __global__ __launch_bounds__(256) void k_bitshuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
                                                             uint64_t n, uint64_t ngroups, uint32_t ts, int inverse,
-                                                            uint64_t g_begin) {
+                                                            uint64_t g_begin, const uint32_t *gate) {
+    if (gate && *gate == 0) return;
     const uint64_t total = ngroups * ts, done = ngroups * 8 * ts;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t idx = g_begin * ts + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -211,22 +216,26 @@ static inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigne
 }
 
 template <int TS>
-static void launch_shuffle_vec(bool inverse, uint8_t *dst, const uint8_t *src, uint64_t ne, uint64_t ntiles, hipStream_t s) {
+static void launch_shuffle_vec(bool inverse, uint8_t *dst, const uint8_t *src, uint64_t ne, uint64_t ntiles, const uint32_t *gate, hipStream_t s) {
     const unsigned grid = grid_for(ntiles, 4, 256 * 8);
-    if (!inverse) hipLaunchKernelGGL(k_shuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles);
-    else hipLaunchKernelGGL(k_unshuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles);
+    if (!inverse) hipLaunchKernelGGL(k_shuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles, gate);
+    else hipLaunchKernelGGL(k_unshuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles, gate);
 }
 
-static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, hipStream_t s);
+static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, const uint32_t *gate, hipStream_t s);
 int hb_launch_filter(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, hipStream_t s) {
     static const char *names[4] = {"filter_shuffle", "filter_unshuffle", "filter_bitshuffle", "filter_bitunshuffle"};
     if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
     hb_prof_begin(names[op], s);
-    const int rc = launch_filter_impl(op, dst, src, n, typesize, s);
+    const int rc = launch_filter_impl(op, dst, src, n, typesize, nullptr, s);
     hb_prof_end(s);
     return rc;
 }
-static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, hipStream_t s) {
+int hb_launch_filter_gated(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, const uint32_t *gate, hipStream_t s) {
+    if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
+    return launch_filter_impl(op, dst, src, n, typesize, gate, s);
+}
+static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, const uint32_t *gate, hipStream_t s) {
     if (n == 0) return HB_OK;
     if (typesize <= 1 || n < (size_t)typesize) {        // shuffle.go:17-19 etc.: identity
         HB_HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
@@ -240,10 +249,10 @@ static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n
             ntiles = ne / TILE_ELEMS;
             if (ntiles) {
                 switch (ts) {
-                case 2: launch_shuffle_vec<2>(inv, dst, src, ne, ntiles, s); break;
-                case 4: launch_shuffle_vec<4>(inv, dst, src, ne, ntiles, s); break;
-                case 8: launch_shuffle_vec<8>(inv, dst, src, ne, ntiles, s); break;
-                default: launch_shuffle_vec<16>(inv, dst, src, ne, ntiles, s); break;
+                case 2: launch_shuffle_vec<2>(inv, dst, src, ne, ntiles, gate, s); break;
+                case 4: launch_shuffle_vec<4>(inv, dst, src, ne, ntiles, gate, s); break;
+                case 8: launch_shuffle_vec<8>(inv, dst, src, ne, ntiles, gate, s); break;
+                default: launch_shuffle_vec<16>(inv, dst, src, ne, ntiles, gate, s); break;
                 }
             }
         }
@@ -251,22 +260,22 @@ static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n
         if (e_begin < ne || ne * ts < n) {
             const uint64_t items = (ne - e_begin) * ts + (n - ne * ts);
             hipLaunchKernelGGL(k_shuffle_generic, dim3(grid_for(items, 256, 256 * 16)), dim3(256), 0, s,
-                               dst, src, (uint64_t)n, ne, (uint32_t)ts, e_begin, inv ? 1 : 0);
+                               dst, src, (uint64_t)n, ne, (uint32_t)ts, e_begin, inv ? 1 : 0, gate);
         }
     } else {
         const bool inv = (op == HB_OP_BITUNSHUFFLE);
         const uint64_t ng = ne / 8;
         if (ts == 4 && ng > 0) {
             const unsigned grid = grid_for(ng, 256, 256 * 16);
-            if (!inv) hipLaunchKernelGGL(k_bitshuffle4<false>, dim3(grid), dim3(256), 0, s, dst, src, ng);
-            else hipLaunchKernelGGL(k_bitshuffle4<true>, dim3(grid), dim3(256), 0, s, dst, src, ng);
+            if (!inv) hipLaunchKernelGGL(k_bitshuffle4<false>, dim3(grid), dim3(256), 0, s, dst, src, ng, gate);
+            else hipLaunchKernelGGL(k_bitshuffle4<true>, dim3(grid), dim3(256), 0, s, dst, src, ng, gate);
             if (ng * 32 < n)   // leftover elements + tail bytes only (g_begin = ng: no groups)
                 hipLaunchKernelGGL(k_bitshuffle_generic, dim3(1), dim3(256), 0, s, dst, src, (uint64_t)n, ng, 4u,
-                                   inv ? 1 : 0, ng);
+                                   inv ? 1 : 0, ng, gate);
         } else {
             const uint64_t items = ng * ts + (n - ng * 8 * ts);
             hipLaunchKernelGGL(k_bitshuffle_generic, dim3(grid_for(items, 256, 256 * 16)), dim3(256), 0, s,
-                               dst, src, (uint64_t)n, ng, (uint32_t)ts, inv ? 1 : 0, (uint64_t)0);
+                               dst, src, (uint64_t)n, ng, (uint32_t)ts, inv ? 1 : 0, (uint64_t)0, gate);
         }
     }
     HB_HIP_TRY(hipGetLastError());

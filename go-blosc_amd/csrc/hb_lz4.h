@@ -27,7 +27,9 @@ struct hb_enc_args {
     uint8_t *work; hb_result *result;
     int frame, codec, shuffle, typesize;
     unsigned opts;
-    const uint8_t *memcpy_src;           // what a memcpy frame stores (filtered bytes, or raw with HB_OPT_REFERENCE_MEMCPY)
+    const uint8_t *memcpy_src;           // what a memcpy frame stores (filtered bytes, or raw with HB_OPT_REFERENCE_MEMCPY);
+                                         // NULL with fused_ts: the payload is shuffled in place by a gated filter launch
+    int fused_ts;                        // != 0: src is the UN-filtered input, byte shuffle with this typesize is fused into the matcher
 };
 
 struct hb_dec_args {

@@ -138,25 +138,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 
 #define QCAP 128            // sequence queue slots (flushed 64 at a time)
 
-__global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
-                                              ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
-                                              uint32_t nchunks) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
-    __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];     // {match pos | match len << 16, offset}
-    const int lane = threadIdx.x;
-
-    for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
-        const uint64_t start = (uint64_t)ck * HB_CHUNK;
-        const int len = (int)((n - start) < HB_CHUNK ? (n - start) : HB_CHUNK);
-        const uint8_t *g = src + start;
-        const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
-        // stage the chunk: 16-byte aligned vectors (over-reads stay inside the first/last 16-byte block)
+// One chunk, one wavefront.  The chunk image is in LDS (byte i of the chunk at s_data[sh + i]); s_out / s_tab /
+// s_q are this wave's scratch; the record goes to `rec`, the summary to *dsc.  with_trailing: also append the
+// un-matched tail of the chunk to the record (fused filter: there is no filtered buffer in HBM for k_stitch to
+// take literals from; a chunk without any match then stores its whole image).
+__device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_t sh, const int len,
+                                            uint8_t *s_out, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */,
+                                            ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const int lane) {
+    {
         {
-            const u32x4 *ga = (const u32x4 *)(g - sh);
-            const uint32_t nv = (sh + (uint32_t)len + 15u) >> 4;
-            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_data)[i] = ga[i];
             u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
             for (uint32_t i = lane; i < HSIZE * 2 / 16; i += 64) ((u32x4 *)s_tab)[i] = z;
         }
@@ -335,15 +325,121 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
         }
         while (nq > 0) flush();
         wave_sync();
-        uint8_t *rec = records + (size_t)ck * HB_RSTRIDE;
-        for (int i = lane * 16; i < o; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_out + i);
+        int total = o;
+        if (with_trailing) {
+            if (nseq == 0 && sh == 0) {            // no match at all: the record is the image itself
+                for (int i = lane * 16; i < len; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_data + i);
+                total = 0;
+            } else {
+                const int trail = len - anchor;
+                for (int i = lane; i < trail; i += 64) s_out[o + i] = data[anchor + i];
+                total = o + trail;
+                wave_sync();
+            }
+        }
+        for (int i = lane * 16; i < total; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_out + i);
         if (lane == 0) {
             ChunkDesc d;
             d.lead = nseq ? lead : 0u; d.enc_len = nseq ? (uint32_t)o : 0u;
             d.last_end = nseq ? (uint32_t)anchor : 0u; d.mcode0 = mcode0;
-            desc[ck] = d;
+            *dsc = d;
         }
         wave_sync();
+    }
+#undef RD4
+}
+
+// un-fused: the chunk comes from a linear (already filtered, or never filtered) buffer in HBM
+__global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
+                                              ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
+                                              uint32_t nchunks) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
+    __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
+    const int lane = threadIdx.x;
+    for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
+        const uint64_t start = (uint64_t)ck * HB_CHUNK;
+        const int len = (int)((n - start) < HB_CHUNK ? (n - start) : HB_CHUNK);
+        const uint8_t *g = src + start;
+        const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
+        // stage the chunk: 16-byte aligned vectors (over-reads stay inside the first/last 16-byte block)
+        const u32x4 *ga = (const u32x4 *)(g - sh);
+        const uint32_t nv = (sh + (uint32_t)len + 15u) >> 4;
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_data)[i] = ga[i];
+        match_chunk(s_data, sh, len, s_out, s_tab, s_q, desc + ck, records + (size_t)ck * HB_RSTRIDE, false, lane);
+    }
+}
+
+// Fused byte-shuffle + match (north star: the filter never makes a round trip through HBM).  Chunk  j * nblk + b  of
+// the (never materialised) shuffled buffer is byte j of the elements [b * HB_CHUNK, (b+1) * HB_CHUNK): the wave reads
+// those HB_CHUNK*TS source bytes coalesced (16 B per lane), picks its byte plane with three v_perm_b32 per 4
+// elements, and builds the chunk image in LDS.  The TS waves of a block read the same bytes; they are given
+// workgroup ids that are equal mod 8 (same XCD under round-robin placement: they share the L2 lines -- speed
+// only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
+template <int TS>
+__global__ __launch_bounds__(64) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
+                                                    uint8_t *__restrict__ records, uint32_t nblk) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
+    __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
+    const int lane = threadIdx.x;
+    const uint32_t total = nblk * TS;
+    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+        // i -> (block b, plane j): within a group of 8 blocks, work item (j, b % 8) has index j * 8 + b % 8
+        const uint32_t grp = i / (8u * TS), r = i % (8u * TS);
+        // rotate the plane with the pass number: a workgroup's id fixes r, and planes differ a lot in cost
+        uint32_t b = grp * 8u + (r & 7u), j = ((r >> 3) + i / gridDim.x) % TS;
+        if (grp * 8u + 8u > nblk) {                        // ragged last group: plain (b, j) order
+            const uint32_t k = i - grp * 8u * TS;
+            const uint32_t nb = nblk - grp * 8u;
+            b = grp * 8u + k % nb; j = k / nb;
+        }
+        const uint64_t e0 = (uint64_t)b * HB_CHUNK;        // first element of the block
+        wave_sync();
+        // all loads of a batch are issued before the first use: one HBM round trip per 16 vectors, not 16
+        if constexpr (TS == 2) {
+            const uint32_t sel = j ? 0x07050301u : 0x06040200u;
+            u32x4 v[HB_CHUNK / 512];
+#pragma unroll
+            for (int it = 0; it < (int)(HB_CHUNK / 512); it++)              // 8 elements (16 B) per lane per step
+                v[it] = ld16u(src + (e0 + (uint32_t)it * 512u + (uint32_t)lane * 8u) * 2);
+#pragma unroll
+            for (int it = 0; it < (int)(HB_CHUNK / 512); it++) {
+                u32x2 pl;
+                pl.x = __builtin_amdgcn_perm(v[it].y, v[it].x, sel);
+                pl.y = __builtin_amdgcn_perm(v[it].w, v[it].z, sel);
+                *(u32x2 *)&s_data[(uint32_t)it * 512u + (uint32_t)lane * 8u] = pl;
+            }
+        } else {
+            const uint32_t q = j >> 2, rb = j & 3u;
+            const uint32_t sel = 0x0c0c0000u | ((4u + rb) << 8) | rb;      // {lo.byte rb, hi.byte rb, 0, 0}
+            constexpr int NV = TS / 4;                                      // 16-byte vectors per 4 elements
+            constexpr int BATCH = 16 / NV;                                  // steps per batch (16 vectors in flight)
+#pragma unroll 1
+            for (int it0 = 0; it0 < (int)(HB_CHUNK / 256); it0 += BATCH) {  // 4 elements (4*TS bytes) per lane per step
+                u32x4 v[BATCH][NV];
+#pragma unroll
+                for (int k = 0; k < BATCH; k++)
+#pragma unroll
+                    for (int c = 0; c < NV; c++)
+                        v[k][c] = ld16u(src + (e0 + (uint32_t)(it0 + k) * 256u + (uint32_t)lane * 4u) * TS + c * 16);
+#pragma unroll
+                for (int k = 0; k < BATCH; k++) {
+                    uint32_t w0, w1, w2, w3;                                // the dword holding byte j of elements 0..3
+                    if constexpr (TS == 4) { w0 = v[k][0].x; w1 = v[k][0].y; w2 = v[k][0].z; w3 = v[k][0].w; }
+                    else {                                                  // TS == 8: element = 2 dwords
+                        w0 = q ? v[k][0].y : v[k][0].x; w1 = q ? v[k][0].w : v[k][0].z;
+                        w2 = q ? v[k][1].y : v[k][1].x; w3 = q ? v[k][1].w : v[k][1].z;
+                    }
+                    const uint32_t t = __builtin_amdgcn_perm(w1, w0, sel), u = __builtin_amdgcn_perm(w3, w2, sel);
+                    *(uint32_t *)&s_data[(uint32_t)(it0 + k) * 256u + (uint32_t)lane * 4u] = __builtin_amdgcn_perm(u, t, 0x05040100u);
+                }
+            }
+        }
+        const uint32_t ck = j * nblk + b;
+        match_chunk(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, lane);
     }
 }
 
@@ -472,7 +568,8 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
         const ChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records, const uint8_t *__restrict__ src,
         const Agg *__restrict__ tile_pre, const uint32_t *__restrict__ tile_suf, const EncPlan *__restrict__ plan,
         uint32_t nchunks, uint64_t n, uint8_t *__restrict__ out /* block start */,
-        uint8_t *__restrict__ index_base_ext, uint8_t *__restrict__ frame_base, const uint8_t *__restrict__ memcpy_src) {
+        uint8_t *__restrict__ index_base_ext, uint8_t *__restrict__ frame_base, const uint8_t *__restrict__ memcpy_src,
+        int lit_from_records) {
     __shared__ Agg s[256];
     __shared__ uint32_t s_nf[256];
     __shared__ ChunkDesc s_desc[256];
@@ -485,7 +582,7 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
         const uint64_t b0 = (uint64_t)ck0 * HB_CHUNK;
         const uint64_t b1 = min((uint64_t)(ck0 + cnt) * HB_CHUNK, n);
         for (uint64_t off = b0 + (uint64_t)wave * 16384u; off < b1; off += (uint64_t)NW * 16384u)
-            wave_copy_g2g(out + off, memcpy_src + off, (uint32_t)min((uint64_t)16384u, b1 - off), lane);
+            if (memcpy_src) wave_copy_g2g(out + off, memcpy_src + off, (uint32_t)min((uint64_t)16384u, b1 - off), lane);
         return;
     }
 
@@ -533,9 +630,10 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
             I = O + hdr + carry_lits + cd.enc_len;
             a2 = start + cd.last_end; tpos = a2;
         }
-        // trailing literals (straight from the source): part of the run that ends at NF
+        // trailing literals (from the source, or from the record when the filter was fused): part of the run that ends at NF
         const uint32_t hdr2 = 1 + lz4_ext_bytes(NF - a2);
-        wave_copy_g2g(out + I + hdr2 + (tpos - a2), src + tpos, end - tpos, lane);
+        const uint8_t *lsrc = lit_from_records ? records + (size_t)ck * HB_RSTRIDE + (cd.last_end ? cd.enc_len : 0u) : src + tpos;
+        wave_copy_g2g(out + I + hdr2 + (tpos - a2), lsrc, end - tpos, lane);
         if (ck + 1 == nchunks) wave_write_lit_header(out + I, NF - a2, 0, lane);  // final literal-only sequence
         if (index && lane == 0) {
             uint32_t *e = (uint32_t *)(index + HB_IDX_HDR_BYTES) + 4 * (size_t)ck;
@@ -572,9 +670,19 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
     const int has_index = a.frame ? ((a.opts & HB_OPT_INDEX_TRAILER) ? 1 : 0) : (a.index ? 1 : 0);
 
     if (L.nchunks) {
-        const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;
-        hb_prof_begin("k_match", s);
-        hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks);
+        hb_prof_begin(a.fused_ts ? "k_match_fused" : "k_match", s);
+        if (a.fused_ts) {
+            const uint32_t nblk = L.nchunks / (uint32_t)a.fused_ts;
+            const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;     // multiple of 8 when capped
+            switch (a.fused_ts) {
+            case 2: hipLaunchKernelGGL(k_match_fused<2>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
+            case 4: hipLaunchKernelGGL(k_match_fused<4>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
+            default: hipLaunchKernelGGL(k_match_fused<8>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
+            }
+        } else {
+            const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;
+            hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks);
+        }
         hb_prof_end(s);
         hb_prof_begin("k_tiles", s);
         hipLaunchKernelGGL(k_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg, tile_nf);
@@ -584,11 +692,17 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, s, tile_agg, tile_nf, tile_pre, tile_suf, L.ntiles, L.nchunks,
                        (uint64_t)a.n, plan, a.dst, fi, a.result, has_index);
     hb_prof_end(s);
+    if (a.fused_ts && !a.memcpy_src) {
+        // memcpy fallback of a fused frame (blosc.go:342-345 with the filtered payload): the shuffled bytes were never
+        // written, so shuffle straight into the payload -- the kernel exits at once unless k_scan chose memcpy
+        const int rc = hb_launch_filter_gated(HB_OP_SHUFFLE, out, a.src, a.n, a.fused_ts, &plan->use_memcpy, s);
+        if (rc) return rc;
+    }
     if (L.nchunks) {
         hb_prof_begin("k_stitch", s);
         hipLaunchKernelGGL(k_stitch, dim3(L.ntiles), dim3(STITCH_THREADS), 0, s, desc, records, a.src, tile_pre, tile_suf,
                            plan, L.nchunks, (uint64_t)a.n, out, a.frame ? (uint8_t *)nullptr : a.index,
-                           a.frame ? a.dst : (uint8_t *)nullptr, a.memcpy_src);
+                           a.frame ? a.dst : (uint8_t *)nullptr, a.memcpy_src, a.fused_ts ? 1 : 0);
         hb_prof_end(s);
     }
     HB_HIP_TRY(hipGetLastError());

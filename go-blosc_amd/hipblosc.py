@@ -22,7 +22,7 @@ BloscLZ, LZ4, LZ4HC, Snappy, ZLIB, ZSTD = range(6)
 NoShuffle, Shuffle1, BitShuffle = 0, 1, 2
 flagShuffle, flagMemcpy, flagBitShuffle, flagSplit = 0x1, 0x2, 0x4, 0x8
 OP_SHUFFLE, OP_UNSHUFFLE, OP_BITSHUFFLE, OP_BITUNSHUFFLE = 0, 1, 2, 3
-OPT_INDEX_TRAILER, OPT_REFERENCE_MEMCPY = 0x1, 0x2
+OPT_INDEX_TRAILER, OPT_REFERENCE_MEMCPY, OPT_NO_FUSION = 0x1, 0x2, 0x4
 
 _CODEC_NAMES = {BloscLZ: "blosclz", LZ4: "lz4", LZ4HC: "lz4hc", Snappy: "snappy", ZLIB: "zlib", ZSTD: "zstd"}
 _SHUFFLE_NAMES = {NoShuffle: "noshuffle", Shuffle1: "shuffle", BitShuffle: "bitshuffle"}

@@ -61,6 +61,8 @@ enum { HB_FLAG_SHUFFLE = 0x1, HB_FLAG_MEMCPY = 0x2, HB_FLAG_BITSHUFFLE = 0x4, HB
                                           (the reference then corrupts them on decode); default stores the
                                           filtered bytes so the reference Decompress reproduces the input */
 
+#define HB_OPT_NO_FUSION         0x4u  /* run the filter as its own kernel pass instead of fusing it into the LZ4 kernels (diagnostics / A-B timing) */
+
 /* 16-byte frame header, blosc.go:154-162 */
 typedef struct hb_header {
     uint8_t  version;    /* 2 */

@@ -262,3 +262,28 @@ def test_multi_tile_frames_use_the_index(hb, O):
         cb = hb.GetInfo(f).NBytesComp
         assert hb.Decompress(f[:cb]) == x.tobytes(), f"{name}: serial decode (index cut off) differs"
         assert not (hb.lib().hb_last_result_flags() & 1)
+
+
+@pytest.mark.parametrize("ts", [2, 4, 8])
+def test_fused_shuffle_equals_separate_filter_pass(hb, O, ts):
+    # byte shuffle on whole blocks of 4096 elements is fused into the matcher (no filtered buffer in HBM);
+    # the frame must be byte-identical to the one built with the filter as its own pass
+    rng = np.random.default_rng(ts)
+    blk = 4096 * ts
+    cases = {
+        "f32": O.synth(O.D_F32, 3 * blk // 4 * 4)[: 12 * blk],
+        "f64": O.synth(O.D_F64, 5 * blk // 8 * 8)[: 5 * blk],
+        "noise": rng.integers(0, 256, 7 * blk, dtype=np.uint8),                       # -> memcpy frame
+        "mixed": np.concatenate([rng.integers(0, 256, 2 * blk, dtype=np.uint8), np.zeros(3 * blk, np.uint8),
+                                 O.synth(O.D_I32, blk // 4 * 4)[: 4 * blk]]),
+        "one_block": O.synth(O.D_RAMP, blk // 4),
+    }
+    for name, x in cases.items():
+        assert x.size % blk == 0
+        for base in (0, hb.OPT_INDEX_TRAILER, hb.OPT_REFERENCE_MEMCPY):
+            fused = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.Shuffle1, ts, opts=base)
+            plain = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.Shuffle1, ts, opts=base | hb.OPT_NO_FUSION)
+            assert fused == plain, f"{name} opts={base}: fused frame differs from the two-pass frame"
+            if not (base & hb.OPT_REFERENCE_MEMCPY):
+                assert np.array_equal(O.decompress_frame(np.frombuffer(fused, np.uint8)), x), name
+                assert hb.Decompress(fused) == x.tobytes(), name
