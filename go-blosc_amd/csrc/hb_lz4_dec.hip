@@ -175,7 +175,19 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
     const uint8_t *ent = index + HB_IDX_HDR_BYTES;
     const uint32_t nbytes = plan->nbytes;
 
-    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+    // Units are visited in a scrambled order (u = i * P mod nunits, P odd-ish and coprime to nunits, about
+    // nunits/4): neighbouring workgroups then work on far-apart parts of the buffer (different byte planes of a
+    // shuffled frame: issue-bound token-dense units next to bandwidth-bound literal-only ones), and the odd grid
+    // size rotates the mix from pass to pass.  Any order is correct: units are independent.
+    uint32_t P = nunits / 4u + 1u;
+    for (;;) {                                              // gcd(P, nunits) == 1
+        uint32_t x = P, y = nunits;
+        while (y) { const uint32_t t = x % y; x = y; y = t; }
+        if (x == 1u) break;
+        P++;
+    }
+    for (uint32_t it = blockIdx.x; it < nunits; it += gridDim.x) {
+        const uint32_t u = (uint32_t)(((uint64_t)it * P) % nunits);
         const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
         const uint32_t s0 = e0.x, d0 = e0.y, s1 = e1.x, d1 = e1.y, rem1 = e1.z, tok1 = e1.w;
         uint32_t rem = e0.z, tokpos = e0.w;
@@ -478,7 +490,7 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
     hb_prof_end(s);
     if (a.index) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
-        const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u ? units : 256u * 64u));
+        const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u + 1u ? units : 256u * 64u + 1u));   // odd when capped
         hb_prof_begin("k_dec_indexed", s);
         hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan);
         hb_prof_end(s);
