@@ -17,6 +17,10 @@ struct __attribute__((packed, aligned(1))) hb_u16u { uint16_t v; };
 
 __device__ __forceinline__ u32x4 ld16u(const uint8_t *p) { return ((const hb_u128u *)p)->v; }
 __device__ __forceinline__ void st16u(uint8_t *p, u32x4 v) { ((hb_u128u *)p)->v = v; }
+// streaming variants ("nt": no reuse expected; bypass / do not retain in the caches)
+typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
+__device__ __forceinline__ u32x4 ld16u_nt(const uint8_t *p) { return __builtin_nontemporal_load((const u32x4_a1 *)p); }
+__device__ __forceinline__ void st16u_nt(uint8_t *p, u32x4 v) { __builtin_nontemporal_store(v, (u32x4_a1 *)p); }
 __device__ __forceinline__ uint64_t ld8u(const uint8_t *p) { return ((const hb_u64u *)p)->v; }
 __device__ __forceinline__ void st8u(uint8_t *p, uint64_t v) { ((hb_u64u *)p)->v = v; }
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { return ((const hb_u32u *)p)->v; }

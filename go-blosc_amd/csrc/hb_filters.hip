@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, 
                 uint32_t w[TS];                    // w[e*TS/4 + q] = dword q of element e
 #pragma unroll
                 for (int q = 0; q < TS / 4; q++) {
-                    const u32x4 v = ld16u(p + q * 16);
+                    const u32x4 v = ld16u_nt(p + q * 16);
                     w[q * 4 + 0] = v.x; w[q * 4 + 1] = v.y; w[q * 4 + 2] = v.z; w[q * 4 + 3] = v.w;
                 }
 #pragma unroll
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, 
 #pragma unroll
         for (int j = 0; j < TS; j++) {
             const u32x4 v = *(const u32x4 *)&my[j][lane * 4];
-            st16u(dst + (uint64_t)j * ne + e0 + lane * 16, v);
+            st16u_nt(dst + (uint64_t)j * ne + e0 + lane * 16, v);
         }
         wave_sync();
     }
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst
         const uint64_t e0 = tile * TILE_ELEMS;
 #pragma unroll
         for (int j = 0; j < TS; j++)
-            *(u32x4 *)&my[j][lane * 4] = ld16u(src + (uint64_t)j * ne + e0 + lane * 16);
+            *(u32x4 *)&my[j][lane * 4] = ld16u_nt(src + (uint64_t)j * ne + e0 + lane * 16);
         wave_sync();
         if constexpr (TS == 2) {
 #pragma unroll
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst
 #pragma unroll
                 for (int q = 0; q < TS / 4; q++) {
                     u32x4 v; v.x = w[q * 4 + 0]; v.y = w[q * 4 + 1]; v.z = w[q * 4 + 2]; v.w = w[q * 4 + 3];
-                    st16u(p + q * 16, v);
+                    st16u_nt(p + q * 16, v);
                 }
             }
         }
