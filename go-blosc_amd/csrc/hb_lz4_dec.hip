@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                                                     DecPlan *plan) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_MAX + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[128];     // parsed tokens waiting for their lane
     if (plan->mode != DEC_INDEXED) return;
     const int lane = threadIdx.x;
     const uint32_t nunits = plan->nunits;
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         // outside the staged window, end of the unit inside a literal run); slow == 2 starts at a token,
         // slow == 1 inside the literal run (rem, tok) the unit begins in.  slow == 0: the window parser below.
         int slow = 1;
+        uint32_t nq = 0;                                        // tokens queued in s_tq
         if (rem == HB_IDX_AT_TOKEN) { rem = 0; slow = 0; }
         const uint32_t lim = staged;                            // the window parser only looks at staged bytes
         while (ok && !done) {
@@ -263,85 +265,115 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                 di += mlen;
                 continue;
             }
-            if (si == slen || di == outlen) { at_token = true; done = true; break; }
-            // ---- 64 stream bytes at once: every lane parses "as if a token started at my byte" ----
-            const uint32_t base = si, p = base + (uint32_t)lane;
-            const uint32_t w = dec_read4(s_in, sh + p);
-            const uint32_t t = w & 255u;
-            uint32_t lit = t >> 4, nbl = 0;
-            bool cplx = p >= lim;
-            if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
-            const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
-            if (offpos + 3u > lim) cplx = true;                  // literal-only tail, or too close to the edge
-            const uint32_t x = dec_read4(s_in, sh + (cplx ? 0u : offpos));
-            const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
-            uint32_t mlen = 4u + mn, nbm = 0;
-            if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
-            const uint32_t nxt = offpos + 2u + nbm;
-            // ---- follow the real token chain through the window (scalar: ballot / readlane only) ----
-            const unsigned long long cmask = __ballot(cplx);
-            unsigned long long tmask = 0;
-            uint32_t cur;
-            {
-                // one bit-set + one readlane per token; a "complex" lane ends the walk (its successor is >= 64)
-                const uint32_t nrel = cplx ? 64u : nxt - base;
-                uint32_t j = 0;
-                do {
-                    asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
-                    j = __builtin_amdgcn_readlane(nrel, (int)j);
-                } while (j < 64u);
-                cur = base + j;
-                const unsigned long long cm = tmask & cmask;     // at most the last visited lane
-                if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); }
-            }
-            bool istok = (tmask >> lane) & 1ull;
-            uint32_t olen = istok ? lit + mlen : 0u;
-            const uint32_t incl = dec_incl_scan(olen, lane);
-            const uint32_t dpos = di + incl - olen;
-            uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-            const unsigned long long om = __ballot(istok && dpos + olen > outlen);
-            if (om) {                                            // this sequence passes the end of the unit: slow path
-                const int jx = __builtin_ctzll(om);
-                tmask &= (1ull << jx) - 1ull;
-                cur = base + (uint32_t)jx;
-                total = __builtin_amdgcn_readlane(dpos, jx) - di;
-                istok = istok && lane < jx;
-            }
-            if (tmask == 0) { slow = 2; continue; }
-            // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
-            if (__ballot(istok && (offv == 0u || offv > dpos + lit))) { ok = false; break; }
-            // ---- literals: short runs by their own lane, long runs by the whole wave ----
-            if (istok && lit <= DLITCAP) lds_copy_exact(s_out + dpos, in + lsrc, lit);
-            unsigned long long lm = __ballot(istok && lit > DLITCAP);
-            while (lm) {
-                const int l = __builtin_ctzll(lm);
-                const uint32_t sp = __builtin_amdgcn_readlane(lsrc, l), dp = __builtin_amdgcn_readlane(dpos, l);
-                const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
-                for (uint32_t k = lane; k < ln; k += 64) s_out[dp + k] = in[sp + k];
-                lm &= lm - 1;
-            }
-            // ---- matches: every lane copies its own short match as soon as its source is final.  Everything
-            //      before the first pending match is final, so each round retires at least that one; matches
-            //      longer than DMCAP bytes are copied by the whole wave when they come first. ----
-            const uint32_t mdv = dpos + lit;                               // where my match goes
-            const uint32_t srcend = mdv - offv + (mlen < offv ? mlen : offv); // end of the part of the source that is not my own output
-            unsigned long long pend = tmask;
-            while (pend) {
-                const int f = __builtin_ctzll(pend);
-                const uint32_t X = __builtin_amdgcn_readlane(mdv, f);
-                const uint32_t mlf = __builtin_amdgcn_readlane(mlen, f);
-                if (mlf > DMCAP) {
-                    dec_match_copy(s_out, X, __builtin_amdgcn_readlane(offv, f), mlf, lane);
-                    pend &= pend - 1;
-                    continue;
+            // ---- fill: parse windows of 64 stream bytes until 64 tokens are queued, the slice ends, or a token needs the
+            //      slow path (length extension > 1 byte, too close to the edge of the staged bytes) ----
+            bool stop = false;
+            while (nq < 64u && !stop) {
+                if (si == slen) { stop = true; break; }
+                // every lane parses "as if a token started at my byte"
+                const uint32_t base = si, p = base + (uint32_t)lane;
+                const uint32_t w = dec_read4(s_in, sh + p);
+                const uint32_t t = w & 255u;
+                uint32_t lit = t >> 4, nbl = 0;
+                bool cplx = p >= lim;
+                if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
+                const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
+                if (offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
+                const uint32_t x = dec_read4(s_in, sh + (cplx ? 0u : offpos));
+                const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
+                uint32_t mlen = 4u + mn, nbm = 0;
+                if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
+                const uint32_t nxt = offpos + 2u + nbm;
+                // follow the real token chain through the window: one bit-set + one readlane per token; a
+                // "complex" lane ends the walk (its successor is >= 64)
+                const unsigned long long cmask = __ballot(cplx);
+                unsigned long long tmask = 0;
+                uint32_t cur;
+                {
+                    const uint32_t nrel = cplx ? 64u : nxt - base;
+                    uint32_t j = 0;
+                    do {
+                        asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                        j = __builtin_amdgcn_readlane(nrel, (int)j);
+                    } while (j < 64u);
+                    cur = base + j;
+                    const unsigned long long cm = tmask & cmask;  // at most the last visited lane
+                    if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
                 }
-                // ready: the source ends before the first pending match, or lies inside my own literals
-                const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP && (srcend <= X || offv <= lit);
-                if (ready) lds_match_lane(s_out, mdv, offv, mlen);
-                pend &= ~__ballot(ready);
+                // queue the real tokens, compacted in stream order: {lsrc | lit << 13 | mlen << 22, offset | tokpos << 16}
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+                if ((tmask >> lane) & 1ull) {
+                    uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
+                    s_tq[nq + rank] = e;
+                }
+                nq += (uint32_t)__builtin_popcountll(tmask);
+                si = cur;
             }
-            di += total;
-            si = cur;
+            // ---- drain: one queued token per lane ----
+            bool rewound = false;
+            while (nq >= 64u || (stop && nq > 0u)) {
+                const uint32_t cntb = nq < 64u ? nq : 64u;
+                const uint2 e = s_tq[lane];
+                const uint32_t lsrc = e.x & 0x1FFFu, lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22;
+                const uint32_t offv = e.y & 0xFFFFu, tp = e.y >> 16;
+                const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
+                const uint32_t incl = dec_incl_scan(olen, lane);
+                const uint32_t dpos = di + incl - olen;
+                uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                unsigned long long amask = cntb >= 64u ? ~0ull : ((1ull << cntb) - 1ull);
+                const unsigned long long om = __ballot(olen != 0u && dpos + olen > outlen);
+                if (om) {                                        // this sequence passes the end of the unit: slow path from its token
+                    const int jx = __builtin_ctzll(om);
+                    amask &= (1ull << jx) - 1ull;
+                    total = __builtin_amdgcn_readlane(dpos, jx) - di;
+                    si = __builtin_amdgcn_readlane(tp, jx);
+                    rewound = true;
+                }
+                const bool istok = (amask >> lane) & 1ull;
+                // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
+                if (__ballot(istok && (offv == 0u || offv > dpos + lit))) { ok = false; break; }
+                // literals: short runs by their own lane, long runs by the whole wave
+                if (istok && lit <= DLITCAP) lds_copy_exact(s_out + dpos, in + lsrc, lit);
+                unsigned long long lm = __ballot(istok && lit > DLITCAP);
+                while (lm) {
+                    const int l = __builtin_ctzll(lm);
+                    const uint32_t sp = __builtin_amdgcn_readlane(lsrc, l), dp = __builtin_amdgcn_readlane(dpos, l);
+                    const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
+                    for (uint32_t k = lane; k < ln; k += 64) s_out[dp + k] = in[sp + k];
+                    lm &= lm - 1;
+                }
+                // matches: every lane copies its own short match as soon as its source is final.  Everything before the
+                // first pending match is final, so each round retires at least that one; matches longer than DMCAP
+                // bytes are copied by the whole wave when they come first.
+                const uint32_t mdv = dpos + lit;                               // where my match goes
+                const uint32_t srcend = mdv - offv + (mlen < offv ? mlen : offv); // end of the source that is not my own output
+                unsigned long long pend = amask;
+                while (pend) {
+                    const int f = __builtin_ctzll(pend);
+                    const uint32_t X = __builtin_amdgcn_readlane(mdv, f);
+                    const uint32_t mlf = __builtin_amdgcn_readlane(mlen, f);
+                    if (mlf > DMCAP) {
+                        dec_match_copy(s_out, X, __builtin_amdgcn_readlane(offv, f), mlf, lane);
+                        pend &= pend - 1;
+                        continue;
+                    }
+                    // ready: the source ends before the first pending match, or lies inside my own literals
+                    const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP && (srcend <= X || offv <= lit);
+                    if (ready) lds_match_lane(s_out, mdv, offv, mlen);
+                    pend &= ~__ballot(ready);
+                }
+                di += total;
+                if (rewound) { nq = 0; break; }
+                const uint2 rest = s_tq[64 + lane];              // keep what is queued beyond the 64 just decoded
+                nq -= cntb;
+                if ((uint32_t)lane < nq) s_tq[lane] = rest;
+            }
+            if (!ok) break;
+            if (rewound) { slow = 2; continue; }
+            if (stop) {
+                if (si == slen || di == outlen) { at_token = true; done = true; }
+                else slow = 2;
+            }
         }
         // end-state check against the next entry
         if (ok) {
