@@ -416,7 +416,9 @@ __global__ __launch_bounds__(64) void k_match_fused(const uint8_t *__restrict__ 
             const uint32_t q = j >> 2, rb = j & 3u;
             const uint32_t sel = 0x0c0c0000u | ((4u + rb) << 8) | rb;      // {lo.byte rb, hi.byte rb, 0, 0}
             constexpr int NV = TS / 4;                                      // 16-byte vectors per 4 elements
-            constexpr int BATCH = 16 / NV;                                  // steps per batch (16 vectors in flight)
+            constexpr int STEPS = (int)(HB_CHUNK / 256);
+            constexpr int BATCH = (16 / NV) < STEPS ? (16 / NV) : STEPS;   // steps per batch (<= 16 vectors in flight)
+            static_assert(STEPS % BATCH == 0, "chunk size must be a multiple of the staging batch");
 #pragma unroll 1
             for (int it0 = 0; it0 < (int)(HB_CHUNK / 256); it0 += BATCH) {  // 4 elements (4*TS bytes) per lane per step
                 u32x4 v[BATCH][NV];
