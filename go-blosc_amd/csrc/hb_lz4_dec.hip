@@ -4,11 +4,16 @@
 // An LZ4 block is a serial chain, so there are two decoders:
 //
 //   k_dec_indexed : for blocks that come with a restart index (HBIX, see hb_lz4.h) — every block this
-//       library encodes.  One wavefront per index unit (= one 4 KiB chunk of output): the unit's slice of
-//       the stream is staged in LDS, parsed token by token (wave-uniform), literals and matches are copied
-//       cooperatively into an LDS image of the chunk (overlapping matches via i mod offset, no serial
-//       dependence), and the image is flushed with coalesced 16-byte stores.  The index is NOT trusted:
-//       each unit checks that it ends exactly in the state the next entry claims (stream offset, output
+//       library encodes.  One wavefront per index unit (= one 4 KiB chunk of output), the unit's slice of the
+//       stream staged in LDS.  FILL: the 64 lanes parse 64 stream bytes "as if a token started at my byte"; the
+//       real token chain is followed with one s_bitset1_b64 + one v_readlane per token and the real tokens are
+//       compacted into an LDS queue.  DRAIN: one queued token per lane — a wave scan gives the output positions,
+//       every lane copies its own literals and its own match into an LDS image of the chunk (dependency rounds: a
+//       match is ready when its source ends before the first pending match or lies in the lane's own literals;
+//       overlapping matches by pattern replication), long ones are copied by the whole wave; the image is flushed
+//       with coalesced 16-byte stores.  Literal-only units go HBM -> HBM.  Tokens with multi-byte length
+//       extensions, or at the edges of the unit, take a one-sequence-at-a-time slow path.  The index is NOT
+//       trusted: each unit checks that it ends exactly in the state the next entry claims (stream offset, output
 //       offset, literals left in the current run, token position) and that no match reaches before its
 //       own output.  By induction over the units the result is then byte-identical to a serial decode.
 //       Any violation only raises a flag ...
