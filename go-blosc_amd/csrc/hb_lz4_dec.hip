@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                 // bytes are copied by the whole wave when they come first.
                 const uint32_t mdv = dpos + lit;                               // where my match goes
                 const uint32_t srcend = mdv - offv + (mlen < offv ? mlen : offv); // end of the source that is not my own output
+                const uint32_t mend = mdv + mlen;                              // end of my match
                 unsigned long long pend = amask;
                 while (pend) {
                     const int f = __builtin_ctzll(pend);
@@ -362,8 +363,14 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                         pend &= pend - 1;
                         continue;
                     }
-                    // ready: the source ends before the first pending match, or lies inside my own literals
-                    const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP && (srcend <= X || offv <= lit);
+                    // ready: the source ends before the first pending match, or starts at / after the end of the
+                    // nearest pending match before me (everything between that and my own match is final: literals
+                    // and retired matches; with no pending predecessor that is simply "anything before me")
+                    const unsigned long long below = pend & ((1ull << lane) - 1ull);
+                    const uint32_t pj = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                    const uint32_t pe = (uint32_t)__shfl((int)mend, (int)pj);
+                    const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP &&
+                                       (srcend <= X || below == 0ull || mdv - offv >= pe);
                     if (ready) lds_match_lane(s_out, mdv, offv, mlen);
                     pend &= ~__ballot(ready);
                 }
