@@ -169,6 +169,131 @@ __device__ __forceinline__ void dec_match_copy(uint8_t *s_out, uint32_t md, uint
     }
 }
 
+// FILL: parse windows of 64 stream bytes (in[k] = byte k of the slice, lim = bytes that may be looked at) until 64 tokens
+// are queued, the slice ends, or a token needs the one-at-a-time path (multi-byte length extension, too close to lim).
+// Returns true when it stopped for one of the latter reasons.  Tokens go to s_tq as {lsrc | lit << 13 | mlen << 22,
+// offset | tokpos << 16}, all slice-relative.
+__device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, const uint32_t slen,
+                                         uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si == slen) { stop = true; break; }
+        // every lane parses "as if a token started at my byte"
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t w = dec_read4(s_in, sh + p);
+        const uint32_t t = w & 255u;
+        uint32_t lit = t >> 4, nbl = 0;
+        bool cplx = p >= lim;
+        if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
+        const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
+        if (offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
+        const uint32_t x = dec_read4(s_in, sh + (cplx ? 0u : offpos));
+        const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
+        uint32_t mlen = 4u + mn, nbm = 0;
+        if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
+        const uint32_t nxt = offpos + 2u + nbm;
+        // follow the real token chain through the window: one bit-set + one readlane per token; a
+        // "complex" lane ends the walk (its successor is >= 64)
+        const unsigned long long cmask = __ballot(cplx);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const uint32_t nrel = cplx ? 64u : nxt - base;
+            uint32_t j = 0;
+            do {
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                j = __builtin_amdgcn_readlane(nrel, (int)j);
+            } while (j < 64u);
+            cur = base + j;
+            const unsigned long long cm = tmask & cmask;  // at most the last visited lane
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        // queue the real tokens, compacted in stream order: {lsrc | lit << 13 | mlen << 22, offset | tokpos << 16}
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) {
+            uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
+            s_tq[nq + rank] = e;
+        }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+    }
+    return stop;
+}
+
+// DRAIN: one queued token per lane, while 64 are queued (or `stop` and any are).  out[0] is the first byte of the image,
+// `hist` bytes before it are valid match sources, `outlen` is the room.  A token that does not fit is not decoded:
+// `rewound` is set and si goes back to that token.  Returns false on a match that reaches before out[-hist] or has offset 0.
+__device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, const uint32_t outlen, const uint32_t hist,
+                                          uint32_t &di, uint32_t &si, uint32_t &nq, uint2 *s_tq, const bool stop,
+                                          bool &rewound, const int lane) {
+    bool ok = true;
+    while (nq >= 64u || (stop && nq > 0u)) {
+        const uint32_t cntb = nq < 64u ? nq : 64u;
+        const uint2 e = s_tq[lane];
+        const uint32_t lsrc = e.x & 0x1FFFu, lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22;
+        const uint32_t offv = e.y & 0xFFFFu, tp = e.y >> 16;
+        const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
+        const uint32_t incl = dec_incl_scan(olen, lane);
+        const uint32_t dpos = di + incl - olen;
+        uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        unsigned long long amask = cntb >= 64u ? ~0ull : ((1ull << cntb) - 1ull);
+        const unsigned long long om = __ballot(olen != 0u && dpos + olen > outlen);
+        if (om) {                                        // this sequence passes the end of the unit: slow path from its token
+            const int jx = __builtin_ctzll(om);
+            amask &= (1ull << jx) - 1ull;
+            total = __builtin_amdgcn_readlane(dpos, jx) - di;
+            si = __builtin_amdgcn_readlane(tp, jx);
+            rewound = true;
+        }
+        const bool istok = (amask >> lane) & 1ull;
+        // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
+        if (__ballot(istok && (offv == 0u || offv > dpos + lit + hist))) { ok = false; break; }
+        // literals: short runs by their own lane, long runs by the whole wave
+        if (istok && lit <= DLITCAP) lds_copy_exact(s_out + dpos, in + lsrc, lit);
+        unsigned long long lm = __ballot(istok && lit > DLITCAP);
+        while (lm) {
+            const int l = __builtin_ctzll(lm);
+            const uint32_t sp = __builtin_amdgcn_readlane(lsrc, l), dp = __builtin_amdgcn_readlane(dpos, l);
+            const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
+            for (uint32_t k = lane; k < ln; k += 64) s_out[dp + k] = in[sp + k];
+            lm &= lm - 1;
+        }
+        // matches: every lane copies its own short match as soon as its source is final.  Everything before the
+        // first pending match is final, so each round retires at least that one; matches longer than DMCAP
+        // bytes are copied by the whole wave when they come first.
+        const uint32_t mdv = dpos + lit;                               // where my match goes
+        const int src0 = (int)mdv - (int)offv;                             // < 0: the source starts in the history
+        const int srcend = src0 + (int)(mlen < offv ? mlen : offv);        // end of the source that is not my own output
+        const uint32_t mend = mdv + mlen;                              // end of my match
+        unsigned long long pend = amask;
+        while (pend) {
+            const int f = __builtin_ctzll(pend);
+            const uint32_t X = __builtin_amdgcn_readlane(mdv, f);
+            const uint32_t mlf = __builtin_amdgcn_readlane(mlen, f);
+            if (mlf > DMCAP) {
+                dec_match_copy(s_out, X, __builtin_amdgcn_readlane(offv, f), mlf, lane);
+                pend &= pend - 1;
+                continue;
+            }
+            // ready: the source ends before the first pending match, or starts at / after the end of the
+            // nearest pending match before me (everything between that and my own match is final: literals
+            // and retired matches; with no pending predecessor that is simply "anything before me")
+            const unsigned long long below = pend & ((1ull << lane) - 1ull);
+            const uint32_t pj = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+            const uint32_t pe = (uint32_t)__shfl((int)mend, (int)pj);
+            const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP &&
+                               (srcend <= (int)X || below == 0ull || src0 >= (int)pe);
+            if (ready) lds_match_lane(s_out, mdv, offv, mlen);
+            pend &= ~__ballot(ready);
+        }
+        di += total;
+        if (rewound) { nq = 0; break; }
+        const uint2 rest = s_tq[64 + lane];              // keep what is queued beyond the 64 just decoded
+        nq -= cntb;
+        if ((uint32_t)lane < nq) s_tq[lane] = rest;
+    }
+    return ok;
+}
 __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
                                                     DecPlan *plan) {
@@ -270,116 +395,9 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
                 di += mlen;
                 continue;
             }
-            // ---- fill: parse windows of 64 stream bytes until 64 tokens are queued, the slice ends, or a token needs the
-            //      slow path (length extension > 1 byte, too close to the edge of the staged bytes) ----
-            bool stop = false;
-            while (nq < 64u && !stop) {
-                if (si == slen) { stop = true; break; }
-                // every lane parses "as if a token started at my byte"
-                const uint32_t base = si, p = base + (uint32_t)lane;
-                const uint32_t w = dec_read4(s_in, sh + p);
-                const uint32_t t = w & 255u;
-                uint32_t lit = t >> 4, nbl = 0;
-                bool cplx = p >= lim;
-                if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
-                const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
-                if (offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
-                const uint32_t x = dec_read4(s_in, sh + (cplx ? 0u : offpos));
-                const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
-                uint32_t mlen = 4u + mn, nbm = 0;
-                if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
-                const uint32_t nxt = offpos + 2u + nbm;
-                // follow the real token chain through the window: one bit-set + one readlane per token; a
-                // "complex" lane ends the walk (its successor is >= 64)
-                const unsigned long long cmask = __ballot(cplx);
-                unsigned long long tmask = 0;
-                uint32_t cur;
-                {
-                    const uint32_t nrel = cplx ? 64u : nxt - base;
-                    uint32_t j = 0;
-                    do {
-                        asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
-                        j = __builtin_amdgcn_readlane(nrel, (int)j);
-                    } while (j < 64u);
-                    cur = base + j;
-                    const unsigned long long cm = tmask & cmask;  // at most the last visited lane
-                    if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
-                }
-                // queue the real tokens, compacted in stream order: {lsrc | lit << 13 | mlen << 22, offset | tokpos << 16}
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-                if ((tmask >> lane) & 1ull) {
-                    uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
-                    s_tq[nq + rank] = e;
-                }
-                nq += (uint32_t)__builtin_popcountll(tmask);
-                si = cur;
-            }
-            // ---- drain: one queued token per lane ----
+            const bool stop = dec_fill(s_in, sh, lim, slen, si, nq, s_tq, lane);
             bool rewound = false;
-            while (nq >= 64u || (stop && nq > 0u)) {
-                const uint32_t cntb = nq < 64u ? nq : 64u;
-                const uint2 e = s_tq[lane];
-                const uint32_t lsrc = e.x & 0x1FFFu, lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22;
-                const uint32_t offv = e.y & 0xFFFFu, tp = e.y >> 16;
-                const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
-                const uint32_t incl = dec_incl_scan(olen, lane);
-                const uint32_t dpos = di + incl - olen;
-                uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-                unsigned long long amask = cntb >= 64u ? ~0ull : ((1ull << cntb) - 1ull);
-                const unsigned long long om = __ballot(olen != 0u && dpos + olen > outlen);
-                if (om) {                                        // this sequence passes the end of the unit: slow path from its token
-                    const int jx = __builtin_ctzll(om);
-                    amask &= (1ull << jx) - 1ull;
-                    total = __builtin_amdgcn_readlane(dpos, jx) - di;
-                    si = __builtin_amdgcn_readlane(tp, jx);
-                    rewound = true;
-                }
-                const bool istok = (amask >> lane) & 1ull;
-                // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
-                if (__ballot(istok && (offv == 0u || offv > dpos + lit))) { ok = false; break; }
-                // literals: short runs by their own lane, long runs by the whole wave
-                if (istok && lit <= DLITCAP) lds_copy_exact(s_out + dpos, in + lsrc, lit);
-                unsigned long long lm = __ballot(istok && lit > DLITCAP);
-                while (lm) {
-                    const int l = __builtin_ctzll(lm);
-                    const uint32_t sp = __builtin_amdgcn_readlane(lsrc, l), dp = __builtin_amdgcn_readlane(dpos, l);
-                    const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
-                    for (uint32_t k = lane; k < ln; k += 64) s_out[dp + k] = in[sp + k];
-                    lm &= lm - 1;
-                }
-                // matches: every lane copies its own short match as soon as its source is final.  Everything before the
-                // first pending match is final, so each round retires at least that one; matches longer than DMCAP
-                // bytes are copied by the whole wave when they come first.
-                const uint32_t mdv = dpos + lit;                               // where my match goes
-                const uint32_t srcend = mdv - offv + (mlen < offv ? mlen : offv); // end of the source that is not my own output
-                const uint32_t mend = mdv + mlen;                              // end of my match
-                unsigned long long pend = amask;
-                while (pend) {
-                    const int f = __builtin_ctzll(pend);
-                    const uint32_t X = __builtin_amdgcn_readlane(mdv, f);
-                    const uint32_t mlf = __builtin_amdgcn_readlane(mlen, f);
-                    if (mlf > DMCAP) {
-                        dec_match_copy(s_out, X, __builtin_amdgcn_readlane(offv, f), mlf, lane);
-                        pend &= pend - 1;
-                        continue;
-                    }
-                    // ready: the source ends before the first pending match, or starts at / after the end of the
-                    // nearest pending match before me (everything between that and my own match is final: literals
-                    // and retired matches; with no pending predecessor that is simply "anything before me")
-                    const unsigned long long below = pend & ((1ull << lane) - 1ull);
-                    const uint32_t pj = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-                    const uint32_t pe = (uint32_t)__shfl((int)mend, (int)pj);
-                    const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP &&
-                                       (srcend <= X || below == 0ull || mdv - offv >= pe);
-                    if (ready) lds_match_lane(s_out, mdv, offv, mlen);
-                    pend &= ~__ballot(ready);
-                }
-                di += total;
-                if (rewound) { nq = 0; break; }
-                const uint2 rest = s_tq[64 + lane];              // keep what is queued beyond the 64 just decoded
-                nq -= cntb;
-                if ((uint32_t)lane < nq) s_tq[lane] = rest;
-            }
+            ok = dec_drain(in, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
             if (!ok) break;
             if (rewound) { slow = 2; continue; }
             if (stop) {
@@ -422,16 +440,27 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
     }
 }
 
-// agent-scope relaxed byte load: served by L2, never by this CU's L1 (the wave re-reads bytes it stored)
-__device__ __forceinline__ uint8_t ld_l2(const uint8_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// ------------------------------------------------------------------------------------------------------------
+// k_dec_serial: streams without (or with a rejected) index, e.g. frames written by the reference.  One wavefront,
+// whole block, front to back -- an LZ4 block is one serial chain and nothing says where its tokens are.  It still
+// uses the window-parallel token parser and the lane-parallel copies of the indexed decoder: the stream is staged
+// through an 8 KiB LDS window, the output is built in an LDS image that keeps the last 64 KiB as match history
+// (offsets are 16 bits) in front of a 32 KiB page; the page is flushed to HBM with 16-byte stores and the image is
+// shifted down.  Semantics of lz4.UncompressBlock (restated in oracle/blosc_oracle.c ob_lz4_decompress): empty
+// input -> 0 bytes; the stream may end right after a match; offset 0, offset before the start of the block,
+// truncated input and output overflow are errors.
+// ------------------------------------------------------------------------------------------------------------
+#define SER_WIN   8192u
+#define SER_HIST  65536u
+#define SER_PAGE  32768u      // room for output between flushes
+#define SER_SOFT  16384u      // flush when the page holds this much
 
-// One wavefront, whole block, front to back.  Semantics of lz4.UncompressBlock (see oracle/blosc_oracle.c
-// ob_lz4_decompress for the restated rules).
 __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ src, uint64_t n_src,
                                                    uint8_t *__restrict__ dst, uint64_t cap, DecPlan *plan,
                                                    hb_result *result, int frame, uint32_t expect) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[SER_WIN + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[SER_HIST + SER_PAGE + 1024];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[128];
     const int lane = threadIdx.x;
     if (plan->mode == DEC_INDEXED && !plan->fail) {
         if (lane == 0) {
@@ -441,74 +470,141 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
         }
         return;
     }
-    uint64_t si = 0, di = 0;
+    uint8_t *out = s_img + SER_HIST;         // out[i], i in [-SER_HIST, SER_PAGE): output byte gbase + i
+    uint64_t gbase = 0;                      // output bytes already flushed to dst
+    uint32_t di = 0;                         // bytes in the page
+    uint64_t wpos = 0;                       // stream position of the window
+    uint32_t wlen = 0, wsh = 0;              // s_win[wsh + k] = src[wpos + k], k < wlen
+    uint64_t si = 0;                         // stream position
     int err = 0;
-    while (si < n_src) {
-        const uint32_t b = src[si++];
-        uint64_t ll = b >> 4;
-        if (ll == 15) {
-            for (;;) {
-                if (si >= n_src) { err = 1; break; }
-                const uint32_t x = src[si++];
-                ll += x;
-                if (x != 255u) break;
+    bool fin = false;
+
+    auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+        const uint8_t *g = src + at;
+        wsh = (uint32_t)((uintptr_t)g & 15u);
+        const uint64_t left = n_src - at;
+        wlen = (uint32_t)(left < (uint64_t)(SER_WIN - 16u) ? left : (uint64_t)(SER_WIN - 16u));
+        const u32x4 *ga = (const u32x4 *)(g - wsh);
+        const uint32_t nv = (wsh + wlen + 15u) >> 4;
+        wave_sync();
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+        wpos = at;
+        wave_sync();
+    };
+    // write the first fl (multiple of 16) page bytes to dst and slide the image down by fl
+    auto flush = [&](bool all) __attribute__((always_inline)) {
+        const uint32_t fl = all ? di : (di & ~15u);
+        if (fl == 0) return;
+        wave_sync();
+        uint8_t *o = dst + gbase;
+        for (uint32_t i = lane * 16u; i + 16u <= fl; i += 1024u) st16u(o + i, *(const u32x4 *)(out + i));
+        const uint32_t tail0 = fl & ~15u;
+        if (tail0 + lane < fl) o[tail0 + lane] = out[tail0 + lane];
+        if (!all) {
+            const uint32_t mv = SER_HIST + (di - fl);                 // bytes that stay: history + the unflushed tail
+            for (uint32_t k = lane * 16u; k < mv; k += 1024u) {       // ascending, 1 KiB per step: reads run ahead of writes
+                const u32x4 v = *(const u32x4 *)(s_img + fl + k);
+                *(u32x4 *)(s_img + k) = v;
             }
-            if (err) break;
+            wave_sync();
         }
-        if (ll) {
-            if (ll > n_src - si || ll > cap - di) { err = 1; break; }
-            for (uint64_t off = 0; off < ll; off += 1u << 30) {
-                const uint32_t part = (uint32_t)min((uint64_t)1u << 30, ll - off);
-                wave_copy_g2g(dst + di + off, src + si + off, part, lane);
+        gbase += fl; di -= fl;
+    };
+
+    uint64_t lrem = 0, mrem = 0;             // literals / match bytes of the current sequence still to copy
+    uint32_t moff = 0, tok = 0;
+    int phase = 0;                           // 0 token, 1 literals, 2 offset + match length, 3 match
+    uint32_t nq = 0;
+    if (n_src) refill(0); else fin = true;
+    while (!err && !fin) {
+        if (gbase + di > cap) { err = 1; break; }              // before anything reaches dst
+        if (di >= SER_SOFT) flush(false);
+        const uint32_t room = SER_PAGE - di;
+        if (phase == 0) {
+            if (si == n_src) { fin = true; break; }                   // ran out of input at a token boundary: done
+            // keep a comfortable look-ahead in the window
+            if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+            uint32_t rel = (uint32_t)(si - wpos);
+            // ---- fast path: window-parallel parse, lane-parallel copies ----
+            const uint32_t hist = (uint32_t)(gbase < (uint64_t)SER_HIST ? gbase : (uint64_t)SER_HIST);
+            const bool stop = dec_fill(s_win, wsh, wlen, wlen, rel, nq, s_tq, lane);
+            bool rewound = false;
+            if (!dec_drain(s_win + wsh, out, SER_PAGE, hist, di, rel, nq, s_tq, true, rewound, lane)) { err = 1; break; }
+            const bool moved = (wpos + rel) != si;
+            si = wpos + rel;
+            if (rewound) continue;                                    // page full: flush, then go on from that token
+            if (moved && !stop) continue;
+            if (si == n_src) { fin = true; break; }
+            if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src) continue;    // stopped at the window edge: refill first
+            // ---- one token the slow way (length extensions of any size, literal runs of any size) ----
+            if (si < wpos || si >= wpos + wlen) refill(si);
+            rel = (uint32_t)(si - wpos);
+            tok = s_win[wsh + rel];
+            rel++;
+            uint32_t ll = tok >> 4;
+            if (ll == 15u) {
+                const uint64_t span = n_src - wpos;
+                if (!dec_read_ext(s_win + wsh, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { err = 1; break; }
             }
-            si += ll; di += ll;
+            si = wpos + rel;
+            lrem = ll;
+            phase = 1;
+            continue;
         }
-        uint64_t ml = b & 15u;
-        if (si == n_src && ml == 0) break;
-        if (si >= n_src || n_src - si < 2) { err = 1; break; }
-        const uint32_t offset = (uint32_t)src[si] | ((uint32_t)src[si + 1] << 8);
-        if (offset == 0) { err = 1; break; }
-        si += 2;
-        ml += 4;
-        if (ml == 19) {
-            for (;;) {
-                if (si >= n_src) { err = 1; break; }
-                const uint32_t x = src[si++];
-                ml += x;
-                if (x != 255u) break;
+        if (phase == 1) {
+            if (lrem) {
+                const uint32_t take = (uint32_t)(lrem < (uint64_t)room ? lrem : (uint64_t)room);
+                if (take == 0) { flush(false); continue; }
+                if ((uint64_t)take > n_src - si || gbase + di + take > cap) { err = 1; break; }
+                const uint8_t *g = src + si;
+                for (uint32_t k = lane; k < take; k += 64) out[di + k] = g[k];
+                si += take; di += take; lrem -= take;
+                continue;
             }
-            if (err) break;
+            if (si == n_src) {
+                if ((tok & 15u) != 0u) err = 1;                       // input ends after literals but a match was announced
+                fin = true;
+                break;
+            }
+            phase = 2;
+            continue;
         }
-        if (di < offset || ml > cap - di) { err = 1; break; }
-        // the source bytes were stored by this wave: wait for the stores, then read them from L2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint8_t *m = dst + di - offset;
-        if (offset >= 64u) {
-            for (uint64_t b0 = 0; b0 < ml; b0 += 64) {
-                const uint64_t i = b0 + lane;
-                uint8_t v = 0;
-                if (i < ml) v = ld_l2(m + i);
-                if (i < ml) dst[di + i] = v;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (phase == 2) {
+            if (n_src - si < 2) { err = 1; break; }
+            moff = (uint32_t)src[si] | ((uint32_t)src[si + 1] << 8);
+            si += 2;
+            if (moff == 0) { err = 1; break; }
+            uint32_t ml = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u) {
+                if (si < wpos || si - wpos + 64u > wlen) refill(si);
+                uint32_t rel = (uint32_t)(si - wpos);
+                const uint64_t span = n_src - wpos;
+                if (!dec_read_ext(s_win + wsh, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ml, lane)) { err = 1; break; }
+                si = wpos + rel;
             }
-        } else {
-            uint32_t mm = (uint32_t)lane % offset;
-            const uint32_t step = 64u % offset;
-            uint8_t pat = ld_l2(m + mm);
-            for (uint64_t b0 = 0; b0 < ml; b0 += 64) {
-                const uint64_t i = b0 + lane;
-                if (step) pat = ld_l2(m + mm);
-                if (i < ml) dst[di + i] = pat;
-                mm += step; if (mm >= offset) mm -= offset;
-            }
+            if ((uint64_t)moff > gbase + di) { err = 1; break; }      // before the start of the block (no dictionary)
+            mrem = ml;
+            phase = 3;
+            continue;
         }
-        di += ml;
+        {   // phase 3: match, in pieces that fit the page
+            const uint32_t take = (uint32_t)(mrem < (uint64_t)room ? mrem : (uint64_t)room);
+            if (take == 0) { flush(false); continue; }
+            if (gbase + di + take > cap) { err = 1; break; }
+            wave_sync();
+            dec_match_copy(out, di, moff, take, lane);
+            di += take; mrem -= take;
+            if (mrem == 0) phase = 0;
+        }
     }
+    if (!err && gbase + di > cap) err = 1;
+    if (!err) flush(true);
     if (lane == 0) {
-        result->flags = 0;
-        if (err) { result->status = HB_ERR_DECOMPRESSION_FAILED; result->bytes = 0; }            // blosc.go:411-413
-        else if (frame && di != expect) { result->status = HB_ERR_SIZE_MISMATCH; result->bytes = di; }   // blosc.go:429-431
-        else { result->status = HB_OK; result->bytes = di; }
+        const uint64_t got = gbase + di;
+        result->flags = 0; result->total_bytes = 0;
+        if (err) { result->status = HB_ERR_DECOMPRESSION_FAILED; result->bytes = 0; }                    // blosc.go:411-413
+        else if (frame && got != expect) { result->status = HB_ERR_SIZE_MISMATCH; result->bytes = got; }   // blosc.go:429-431
+        else { result->status = HB_OK; result->bytes = got; }
     }
 }
 
