@@ -557,7 +557,15 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
                 if (take == 0) { flush(false); continue; }
                 if ((uint64_t)take > n_src - si || gbase + di + take > cap) { err = 1; break; }
                 const uint8_t *g = src + si;
-                for (uint32_t k = lane; k < take; k += 64) out[di + k] = g[k];
+                uint32_t k0 = 0;
+                for (; k0 + 4096u <= take; k0 += 4096u) {                // 4 x 16 B per lane in flight
+                    u32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = ld16u(g + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ((hb_u128u *)(out + di + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u))->v = v[q];
+                }
+                for (uint32_t k = k0 + lane; k < take; k += 64) out[di + k] = g[k];
                 si += take; di += take; lrem -= take;
                 continue;
             }

@@ -35,6 +35,15 @@ var MinOffloadBytes = 1 << 20
 // Device used by the host-pointer entry points.
 var Device = 0
 
+// ForceDeviceDecode sends frames without a restart index to the device's single-wavefront decoder too.
+var ForceDeviceDecode = false
+
+// hasRestartIndex: is there an "HBIX" index after NBytesComp (written by CompressHIP(..., withIndex=true))?
+func hasRestartIndex(data []byte, h *Header) bool {
+	off := (int(h.NBytesComp) + 7) &^ 7
+	return len(data) >= off+64 && string(data[off:off+4]) == "HBIX"
+}
+
 var useHIP bool
 
 func init() {
@@ -165,6 +174,12 @@ func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 		return nil, err
 	}
 	if !useHIP || int(h.NBytesOrig) < MinOffloadBytes || (!h.IsMemcpy() && Codec(h.VersionLZ) != LZ4 && Codec(h.VersionLZ) != LZ4HC) {
+		return DecompressWithSize(data, typeSize)
+	}
+	// An LZ4 block is one serial chain: without the restart index the device can only put ONE wavefront on it
+	// (~0.15-0.4 GB/s, measured), slower than the pure-Go decoder.  Such frames (anything the CPU path wrote)
+	// stay on the CPU unless the caller insists.
+	if !h.IsMemcpy() && !hasRestartIndex(data, h) && !ForceDeviceDecode {
 		return DecompressWithSize(data, typeSize)
 	}
 	buf := make([]byte, int(h.NBytesOrig))
