@@ -317,8 +317,11 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
     // byte shuffle with typesize 2/4/8 on whole blocks of HB_CHUNK elements is fused into the matcher
     const bool fused = filt && shuffle == HB_SHUFFLE && (typesize == 2 || typesize == 4 || typesize == 8) &&
                        n % ((size_t)typesize * HB_CHUNK) == 0 && !(opts & HB_OPT_NO_FUSION);
+    // bitshuffle with typesize 4 is a transform inside every 32-byte window: fused when there are only whole windows
+    const bool fused_bits = filt && shuffle == HB_BITSHUFFLE && typesize == 4 && n % 32 == 0 &&
+                            ((uintptr_t)d_src & 15u) == 0 && !(opts & HB_OPT_NO_FUSION);
     const uint8_t *in = (const uint8_t *)d_src;
-    if (filt && !fused) {
+    if (filt && !fused && !fused_bits) {
         int rc = hb_launch_filter(shuffle == HB_SHUFFLE ? HB_OP_SHUFFLE : HB_OP_BITSHUFFLE, filtered,
                                   (const uint8_t *)d_src, n, typesize, s);
         if (rc) return rc;
@@ -329,8 +332,9 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
     a.work = enc_work; a.result = d_result;
     a.frame = 1; a.codec = codec; a.shuffle = shuffle; a.typesize = typesize; a.opts = opts;
     a.fused_ts = fused ? typesize : 0;
+    a.fused_bits = fused_bits ? 4 : 0;
     // what a memcpy frame stores: blosc.go:343-345 (raw input) vs the round-trip-safe filtered bytes
-    a.memcpy_src = (opts & HB_OPT_REFERENCE_MEMCPY) ? (const uint8_t *)d_src : (fused ? nullptr : in);
+    a.memcpy_src = (opts & HB_OPT_REFERENCE_MEMCPY) ? (const uint8_t *)d_src : ((fused || fused_bits) ? nullptr : in);
     return hb_launch_lz4_encode(a, s);
 }
 
@@ -359,13 +363,20 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
     uint8_t *work = (uint8_t *)d_work;
     uint8_t *staged = work;
     uint8_t *dec_work = work + (((size_t)h.nbytes + 255) & ~(size_t)255) + 256;
-    uint8_t *target = (unf >= 0) ? staged : (uint8_t *)d_dst;
+    // bit-unshuffle with typesize 4 works inside 32-byte windows: fused into the indexed decoder when there are only
+    // whole windows (the serial fallback still goes through `staged` + a gated un-filter pass, hb_lz4_dec.hip)
+    const bool fused_bun = unf == HB_OP_BITUNSHUFFLE && ts == 4 && (h.nbytes % 32u) == 0 && !(h.flags & HB_FLAG_MEMCPY) &&
+                           ((uintptr_t)d_dst & 15u) == 0;
+    uint8_t *target = (unf >= 0 && !fused_bun) ? staged : (uint8_t *)d_dst;
     const uint8_t *payload = (const uint8_t *)d_frame + HB_HEADER_SIZE;
     const size_t plen = h.cbytes - HB_HEADER_SIZE;
     hb_dec_args a{};
     a.src = payload; a.n = plen; a.dst = target; a.cap = h.nbytes;
     a.work = dec_work; a.result = d_result; a.frame = 1; a.expect = h.nbytes;
     a.memcpy_payload = (h.flags & HB_FLAG_MEMCPY) ? 1 : 0;            // blosc.go:398-400
+    a.fused_bitunshuffle4 = fused_bun ? 1 : 0;
+    a.staged = staged;
+    if (fused_bun) unf = -1;                                          // nothing left to do after the decoder
     // restart index, if any, sits after cbytes (ignored by the reference decoder, blosc.go:385-393)
     const size_t ioff = ((size_t)h.cbytes + 7) & ~(size_t)7;
     if (!a.memcpy_payload && n > ioff + 32) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }

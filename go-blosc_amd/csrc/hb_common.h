@@ -61,6 +61,34 @@ __device__ __forceinline__ uint64_t bit_transpose8x8_msb(uint64_t x) {
     return x;
 }
 
+// go-blosc's bitshuffle for typesize 4 on ONE window of 8 elements = 32 bytes (a = bytes 0..15, b = 16..31),
+// shuffle.go:184-200 (forward) and :261-277 (inverse).  Output layout: 8 bytes per byte position.
+template <bool INVERSE>
+__device__ __forceinline__ void bitshuffle4_window(const u32x4 a, const u32x4 b, u32x4 &oa, u32x4 &ob) {
+    if (!INVERSE) {
+        // gather byte position bp of the 8 elements -> 8 bytes, bit-transpose, store at window + 8*bp
+        uint32_t l0, l1, l2, l3, h0, h1, h2, h3;
+        transpose4x4(a.x, a.y, a.z, a.w, l0, l1, l2, l3);   // l[bp] = byte bp of elements 0..3
+        transpose4x4(b.x, b.y, b.z, b.w, h0, h1, h2, h3);   // h[bp] = byte bp of elements 4..7
+        const uint64_t y0 = bit_transpose8x8_msb(((uint64_t)h0 << 32) | l0);
+        const uint64_t y1 = bit_transpose8x8_msb(((uint64_t)h1 << 32) | l1);
+        const uint64_t y2 = bit_transpose8x8_msb(((uint64_t)h2 << 32) | l2);
+        const uint64_t y3 = bit_transpose8x8_msb(((uint64_t)h3 << 32) | l3);
+        oa.x = (uint32_t)y0; oa.y = (uint32_t)(y0 >> 32); oa.z = (uint32_t)y1; oa.w = (uint32_t)(y1 >> 32);
+        ob.x = (uint32_t)y2; ob.y = (uint32_t)(y2 >> 32); ob.z = (uint32_t)y3; ob.w = (uint32_t)(y3 >> 32);
+    } else {
+        // 8 bytes at window + 8*bp -> transpose -> byte e goes to element e, byte position bp
+        const uint64_t y0 = bit_transpose8x8_msb(((uint64_t)a.y << 32) | a.x);
+        const uint64_t y1 = bit_transpose8x8_msb(((uint64_t)a.w << 32) | a.z);
+        const uint64_t y2 = bit_transpose8x8_msb(((uint64_t)b.y << 32) | b.x);
+        const uint64_t y3 = bit_transpose8x8_msb(((uint64_t)b.w << 32) | b.z);
+        uint32_t e0, e1, e2, e3, e4, e5, e6, e7;
+        transpose4x4((uint32_t)y0, (uint32_t)y1, (uint32_t)y2, (uint32_t)y3, e0, e1, e2, e3);
+        transpose4x4((uint32_t)(y0 >> 32), (uint32_t)(y1 >> 32), (uint32_t)(y2 >> 32), (uint32_t)(y3 >> 32), e4, e5, e6, e7);
+        oa.x = e0; oa.y = e1; oa.z = e2; oa.w = e3; ob.x = e4; ob.y = e5; ob.z = e6; ob.w = e7;
+    }
+}
+
 #define HB_HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return HB_ERR_HIP; } while (0)
 
 // ---- stage timing for bench.py (hb_profile_*): HIP events on the launch stream around each kernel ----

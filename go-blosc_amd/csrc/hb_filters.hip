@@ -149,29 +149,7 @@ __global__ __launch_bounds__(256) void k_bitshuffle4(uint8_t *__restrict__ dst, 
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
         const u32x4 a = ld16u(src + g * 32), b = ld16u(src + g * 32 + 16);
         u32x4 oa, ob;
-        if (!INVERSE) {
-            // gather byte position bp of the 8 elements -> 8 bytes, bit-transpose, store at window + 8*bp
-            uint32_t l0, l1, l2, l3, h0, h1, h2, h3;
-            transpose4x4(a.x, a.y, a.z, a.w, l0, l1, l2, l3);   // l[bp] = byte bp of elements 0..3
-            transpose4x4(b.x, b.y, b.z, b.w, h0, h1, h2, h3);   // h[bp] = byte bp of elements 4..7
-            const uint64_t y0 = bit_transpose8x8_msb(((uint64_t)h0 << 32) | l0);
-            const uint64_t y1 = bit_transpose8x8_msb(((uint64_t)h1 << 32) | l1);
-            const uint64_t y2 = bit_transpose8x8_msb(((uint64_t)h2 << 32) | l2);
-            const uint64_t y3 = bit_transpose8x8_msb(((uint64_t)h3 << 32) | l3);
-            oa.x = (uint32_t)y0; oa.y = (uint32_t)(y0 >> 32); oa.z = (uint32_t)y1; oa.w = (uint32_t)(y1 >> 32);
-            ob.x = (uint32_t)y2; ob.y = (uint32_t)(y2 >> 32); ob.z = (uint32_t)y3; ob.w = (uint32_t)(y3 >> 32);
-        } else {
-            // 8 bytes at window + 8*bp -> transpose -> byte e goes to element e, byte position bp
-            const uint64_t y0 = bit_transpose8x8_msb(((uint64_t)a.y << 32) | a.x);
-            const uint64_t y1 = bit_transpose8x8_msb(((uint64_t)a.w << 32) | a.z);
-            const uint64_t y2 = bit_transpose8x8_msb(((uint64_t)b.y << 32) | b.x);
-            const uint64_t y3 = bit_transpose8x8_msb(((uint64_t)b.w << 32) | b.z);
-            uint32_t e0, e1, e2, e3, e4, e5, e6, e7;
-            transpose4x4((uint32_t)y0, (uint32_t)y1, (uint32_t)y2, (uint32_t)y3, e0, e1, e2, e3);
-            transpose4x4((uint32_t)(y0 >> 32), (uint32_t)(y1 >> 32), (uint32_t)(y2 >> 32), (uint32_t)(y3 >> 32),
-                         e4, e5, e6, e7);
-            oa.x = e0; oa.y = e1; oa.z = e2; oa.w = e3; ob.x = e4; ob.y = e5; ob.z = e6; ob.w = e7;
-        }
+        bitshuffle4_window<INVERSE>(a, b, oa, ob);
         st16u(dst + g * 32, oa);
         st16u(dst + g * 32 + 16, ob);
     }

@@ -30,6 +30,7 @@ struct hb_enc_args {
     const uint8_t *memcpy_src;           // what a memcpy frame stores (filtered bytes, or raw with HB_OPT_REFERENCE_MEMCPY);
                                          // NULL with fused_ts: the payload is shuffled in place by a gated filter launch
     int fused_ts;                        // != 0: src is the UN-filtered input, byte shuffle with this typesize is fused into the matcher
+    int fused_bits;                      // 4: src is the UN-filtered input, bitshuffle (typesize 4) is fused into the matcher
 };
 
 struct hb_dec_args {
@@ -39,6 +40,8 @@ struct hb_dec_args {
     uint8_t *work; hb_result *result;
     int frame; uint32_t expect;          // frame != 0: decoded length must equal expect (blosc.go:429-431)
     int memcpy_payload;                  // blosc.go:398-400
+    int fused_bitunshuffle4;             // the frame is bitshuffled with typesize 4 and the un-filter runs inside the decoder
+    uint8_t *staged;                     // fused_bitunshuffle4: where the serial fallback puts the still-filtered bytes
 };
 
 size_t hb_lz4_enc_workspace(size_t n);

@@ -30,6 +30,8 @@ struct DecPlan {
     uint32_t fail;        // set by any indexed unit that cannot vouch for its slice
     uint32_t nunits;
     uint32_t nbytes;      // decoded size the index declares
+    uint32_t post;        // set by k_dec_serial when it decoded into the staging buffer: the gated un-filter must run
+    uint32_t pad[3];
 };
 enum { DEC_SERIAL = 0, DEC_INDEXED = 1 };
 
@@ -40,7 +42,7 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return ld4u(p); }
 // 1 thread: is there a usable index?
 __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_bytes, uint64_t n_src, uint64_t cap,
                            DecPlan *plan, hb_result *result) {
-    plan->mode = DEC_SERIAL; plan->fail = 0; plan->nunits = 0; plan->nbytes = 0;
+    plan->mode = DEC_SERIAL; plan->fail = 0; plan->nunits = 0; plan->nbytes = 0; plan->post = 0;
     result->status = HB_OK; result->flags = 0; result->bytes = 0; result->total_bytes = 0; result->reserved = 0;
     if (!index || index_bytes < HB_IDX_HDR_BYTES + 2 * HB_IDX_ENTRY) return;
     uint32_t h[8];
@@ -296,7 +298,9 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, con
 }
 __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
-                                                    DecPlan *plan) {
+                                                    DecPlan *plan, int bun4) {
+    // bun4 != 0: the frame was bitshuffled with typesize 4 -- an in-place transform of every 32-byte window -- and the
+    // un-filter is fused: every unit un-shuffles its own windows before they leave the chip (dst is the final output).
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_MAX + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[128];     // parsed tokens waiting for their lane
@@ -327,6 +331,7 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         if (u == 0) ok = ok && s0 == 0 && d0 == 0 && rem == HB_IDX_AT_TOKEN;
         if (last) ok = ok && s1 == n_src && d1 == nbytes;
         if (rem != HB_IDX_AT_TOKEN && tokpos >= n_src) ok = false;
+        if (bun4 && ((d0 | d1) & 31u)) ok = false;              // fused un-filter works on whole 32-byte windows
         if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
         const uint32_t slen = s1 - s0, outlen = d1 - d0;
         const uint8_t *g = src + s0;
@@ -337,7 +342,15 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             bool fine = slen == outlen;
             if (last) fine = fine && left == 0; else fine = fine && rem1 == left && tok1 == tokpos;
             if (!fine) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
-            wave_copy_g2g(dst + d0, g, outlen, lane);
+            if (!bun4) wave_copy_g2g(dst + d0, g, outlen, lane);
+            else {
+                for (uint32_t w = lane; w < outlen / 32u; w += 64) {
+                    u32x4 oa, ob;
+                    bitshuffle4_window<true>(ld16u(g + 32u * w), ld16u(g + 32u * w + 16u), oa, ob);
+                    st16u(dst + d0 + 32u * w, oa);
+                    st16u(dst + d0 + 32u * w + 16u, ob);
+                }
+            }
             continue;
         }
 
@@ -414,6 +427,15 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         }
         if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); wave_sync(); continue; }
         wave_sync();
+        if (bun4) {                                             // fused bit-unshuffle: every window in place
+            for (uint32_t w = lane; w < outlen / 32u; w += 64) {
+                u32x4 oa, ob;
+                bitshuffle4_window<true>(((const u32x4 *)s_out)[2 * w], ((const u32x4 *)s_out)[2 * w + 1], oa, ob);
+                ((u32x4 *)s_out)[2 * w] = oa;
+                ((u32x4 *)s_out)[2 * w + 1] = ob;
+            }
+            wave_sync();
+        }
         // flush the chunk image
         {
             uint8_t *o = dst + d0;
@@ -457,7 +479,9 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
 
 __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ src, uint64_t n_src,
                                                    uint8_t *__restrict__ dst, uint64_t cap, DecPlan *plan,
-                                                   hb_result *result, int frame, uint32_t expect) {
+                                                   hb_result *result, int frame, uint32_t expect, int mark_post) {
+    // mark_post: dst is a staging buffer (the un-filter was fused into the indexed decoder); when this kernel
+    // really decodes it raises plan->post so that the gated un-filter pass behind it runs
     __shared__ __attribute__((aligned(16))) uint8_t s_win[SER_WIN + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_img[SER_HIST + SER_PAGE + 1024];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[128];
@@ -515,6 +539,7 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
     uint32_t moff = 0, tok = 0;
     int phase = 0;                           // 0 token, 1 literals, 2 offset + match length, 3 match
     uint32_t nq = 0;
+    if (mark_post && lane == 0) plan->post = 1;
     if (n_src) refill(0); else fin = true;
     while (!err && !fin) {
         if (gbase + di > cap) { err = 1; break; }              // before anything reaches dst
@@ -640,13 +665,21 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
         const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u + 1u ? units : 256u * 64u + 1u));   // odd when capped
         hb_prof_begin("k_dec_indexed", s);
-        hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan);
+        hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan,
+                           a.fused_bitunshuffle4);
         hb_prof_end(s);
     }
+    // with a fused un-filter the indexed decoder wrote FINAL bytes to a.dst; the serial decoder (if it has to run)
+    // produces filtered bytes, so it goes to the staging buffer and the gated un-filter pass finishes the job
+    uint8_t *serial_dst = a.fused_bitunshuffle4 ? a.staged : a.dst;
     hb_prof_begin("k_dec_serial", s);
-    hipLaunchKernelGGL(k_dec_serial, dim3(1), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (uint64_t)a.cap, plan,
-                       a.result, a.frame, a.expect);
+    hipLaunchKernelGGL(k_dec_serial, dim3(1), dim3(64), 0, s, a.src, (uint64_t)a.n, serial_dst, (uint64_t)a.cap, plan,
+                       a.result, a.frame, a.expect, a.fused_bitunshuffle4);
     hb_prof_end(s);
+    if (a.fused_bitunshuffle4) {
+        const int rc = hb_launch_filter_gated(HB_OP_BITUNSHUFFLE, a.dst, a.staged, a.expect, 4, &plan->post, s);
+        if (rc) return rc;
+    }
     HB_HIP_TRY(hipGetLastError());
     return HB_OK;
 }

@@ -354,9 +354,12 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 }
 
 // un-fused: the chunk comes from a linear (already filtered, or never filtered) buffer in HBM
+// bits4 != 0: src is the UN-filtered input and go-blosc's bitshuffle for typesize 4 (an in-place transform of every
+// 32-byte window, shuffle.go:184-200) is applied to the chunk image in LDS -- filter fused, no filtered buffer in
+// HBM; the caller guarantees n % 32 == 0 and a 16-byte aligned src.
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
-                                              uint32_t nchunks) {
+                                              uint32_t nchunks, int bits4) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
@@ -370,8 +373,17 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
         // stage the chunk: 16-byte aligned vectors (over-reads stay inside the first/last 16-byte block)
         const u32x4 *ga = (const u32x4 *)(g - sh);
         const uint32_t nv = (sh + (uint32_t)len + 15u) >> 4;
-        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_data)[i] = ga[i];
-        match_chunk(s_data, sh, len, s_out, s_tab, s_q, desc + ck, records + (size_t)ck * HB_RSTRIDE, false, lane);
+        if (!bits4) {
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_data)[i] = ga[i];
+        } else {                                           // sh == 0, len % 32 == 0: one 32-byte window per lane and step
+            for (uint32_t w = lane; w < (uint32_t)len / 32u; w += 64) {
+                u32x4 oa, ob;
+                bitshuffle4_window<false>(ga[2 * w], ga[2 * w + 1], oa, ob);
+                ((u32x4 *)s_data)[2 * w] = oa;
+                ((u32x4 *)s_data)[2 * w + 1] = ob;
+            }
+        }
+        match_chunk(s_data, sh, len, s_out, s_tab, s_q, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, lane);
     }
 }
 
@@ -687,7 +699,7 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
             }
         } else {
             const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;
-            hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks);
+            hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks, a.fused_bits);
         }
         hb_prof_end(s);
         hb_prof_begin("k_tiles", s);
@@ -698,17 +710,17 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, s, tile_agg, tile_nf, tile_pre, tile_suf, L.ntiles, L.nchunks,
                        (uint64_t)a.n, plan, a.dst, fi, a.result, has_index);
     hb_prof_end(s);
-    if (a.fused_ts && !a.memcpy_src) {
+    if ((a.fused_ts || a.fused_bits) && !a.memcpy_src) {
         // memcpy fallback of a fused frame (blosc.go:342-345 with the filtered payload): the shuffled bytes were never
         // written, so shuffle straight into the payload -- the kernel exits at once unless k_scan chose memcpy
-        const int rc = hb_launch_filter_gated(HB_OP_SHUFFLE, out, a.src, a.n, a.fused_ts, &plan->use_memcpy, s);
+        const int rc = hb_launch_filter_gated(a.fused_bits ? HB_OP_BITSHUFFLE : HB_OP_SHUFFLE, out, a.src, a.n, a.fused_bits ? a.fused_bits : a.fused_ts, &plan->use_memcpy, s);
         if (rc) return rc;
     }
     if (L.nchunks) {
         hb_prof_begin("k_stitch", s);
         hipLaunchKernelGGL(k_stitch, dim3(L.ntiles), dim3(STITCH_THREADS), 0, s, desc, records, a.src, tile_pre, tile_suf,
                            plan, L.nchunks, (uint64_t)a.n, out, a.frame ? (uint8_t *)nullptr : a.index,
-                           a.frame ? a.dst : (uint8_t *)nullptr, a.memcpy_src, a.fused_ts ? 1 : 0);
+                           a.frame ? a.dst : (uint8_t *)nullptr, a.memcpy_src, (a.fused_ts || a.fused_bits) ? 1 : 0);
         hb_prof_end(s);
     }
     HB_HIP_TRY(hipGetLastError());

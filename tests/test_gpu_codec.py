@@ -287,3 +287,32 @@ def test_fused_shuffle_equals_separate_filter_pass(hb, O, ts):
             if not (base & hb.OPT_REFERENCE_MEMCPY):
                 assert np.array_equal(O.decompress_frame(np.frombuffer(fused, np.uint8)), x), name
                 assert hb.Decompress(fused) == x.tobytes(), name
+
+
+def test_fused_bitshuffle_equals_separate_filter_pass(hb, O):
+    # bitshuffle (typesize 4) is an in-place transform of 32-byte windows: fused into the matcher and into the
+    # indexed decoder when the frame holds only whole windows; the serial fallback goes through the staging buffer
+    rng = np.random.default_rng(44)
+    cases = {
+        "i32": O.synth(O.D_I32, 40000),                                               # 160000 B, whole windows
+        "f32": O.synth(O.D_F32, 3 * 4096 + 8),
+        "noise": rng.integers(0, 256, 64 * 1024, dtype=np.uint8),                     # -> memcpy frame
+        "ragged": O.synth(O.D_I32, 10001),                                            # 40004 B: not whole windows -> two-pass path
+        "tiny": O.synth(O.D_I32, 8),
+    }
+    for name, x in cases.items():
+        for base in (0, hb.OPT_INDEX_TRAILER, hb.OPT_REFERENCE_MEMCPY):
+            fused = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.BitShuffle, 4, opts=base)
+            plain = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.BitShuffle, 4, opts=base | hb.OPT_NO_FUSION)
+            assert fused == plain, f"{name} opts={base}: fused frame differs from the two-pass frame"
+            if not (base & hb.OPT_REFERENCE_MEMCPY):
+                assert np.array_equal(O.decompress_frame(np.frombuffer(fused, np.uint8)), x), name
+            want = O.decompress_frame(np.frombuffer(fused, np.uint8)).tobytes()
+            assert hb.Decompress(fused) == want, name
+    # tampered index on a bitshuffled frame: indexed decoder refuses, serial decoder + gated un-filter take over
+    x = O.synth(O.D_I32, 1 << 16).tobytes()
+    f = bytearray(hb.Compress(x, hb.LZ4, 5, hb.BitShuffle, 4, opts=hb.OPT_INDEX_TRAILER))
+    assert hb.Decompress(bytes(f)) == x and hb.lib().hb_last_result_flags() & 1
+    ioff = (hb.GetInfo(bytes(f)).NBytesComp + 7) & ~7
+    f[ioff + 32 + 16 * 9 + 4] ^= 0x20
+    assert hb.Decompress(bytes(f)) == x and not (hb.lib().hb_last_result_flags() & 1)
