@@ -394,11 +394,12 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
 int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int codec, int level, int shuffle,
                           int typesize, unsigned opts, int device) {
     if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271 (before anything else)
+    if (!src || !dst) return HB_ERR_BAD_ARG;
+    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;                 // blosc.go:322-325
+    // the header fields are uint32 (blosc.go:159-161); the reference truncates silently (:363-365), this does not
+    if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
     int rc = select_device(device);
     if (rc) return rc;
-    if (!src || !dst) return HB_ERR_BAD_ARG;
-    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;
-    if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
     Scratch sc(device);
     const size_t fb = hb_frame_bound(n), wb = hb_compress_frame_workspace(n);
     uint8_t *d_src = sc.get(n + 16), *d_frame = sc.get(fb + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));

@@ -87,3 +87,16 @@ def test_no_cpu_fallback(hbmod):
         with pytest.raises(hbmod.HipBloscError) as e:
             call()
         assert "no HIP device" in str(e.value)
+
+
+def test_sizes_beyond_uint32_are_refused(hbmod):
+    # the frame header holds uint32 sizes (blosc.go:159-161); the reference truncates silently (:363-365) and never
+    # returns its own ErrDataTooLarge (:142).  Here: HB_ERR_DATA_TOO_LARGE before any byte is touched.
+    L = hbmod.lib()
+    a = ctypes.create_string_buffer(64)
+    b = ctypes.create_string_buffer(64)
+    for n in (0xFFFFFFFF, 1 << 32, 4278190300):          # 16 + n + n//255 + slack no longer fits uint32
+        rc = L.hb_compress_frame(ctypes.addressof(a), n, ctypes.addressof(b), 64, hbmod.LZ4, 5, hbmod.Shuffle1, 4, 0, 0)
+        assert rc == -6, (n, rc)
+    assert L.hb_compress_frame(ctypes.addressof(a), 64, ctypes.addressof(b), 64, 77, 5, 0, 1, 0, 0) == -4    # codec first
+    assert L.hb_strerror(-6) == b"blosc: data too large"

@@ -316,3 +316,29 @@ def test_fused_bitshuffle_equals_separate_filter_pass(hb, O):
     ioff = (hb.GetInfo(bytes(f)).NBytesComp + 7) & ~7
     f[ioff + 32 + 16 * 9 + 4] ^= 0x20
     assert hb.Decompress(bytes(f)) == x and not (hb.lib().hb_last_result_flags() & 1)
+
+
+def test_concurrent_calls_from_many_threads(hb, O):
+    # "All functions ... safe for concurrent use" (blosc.go:37-39): the C ABI is called from 6 OS threads at once
+    import threading
+    xs = [O.synth(O.D_F32, 60000 + 1000 * k, frame=k).tobytes() for k in range(6)]
+    out, errs = [None] * 6, []
+
+    def work(k):
+        try:
+            for _ in range(4):
+                f = hb.Compress(xs[k], hb.LZ4, 5, hb.Shuffle1 if k % 2 else hb.BitShuffle, 4, opts=hb.OPT_INDEX_TRAILER)
+                assert hb.Decompress(f) == xs[k]
+                assert hb.unshuffleBytes(hb.shuffleBytes(xs[k], 4), 4) == xs[k]
+            out[k] = f
+        except Exception as e:          # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for k in range(6):
+        assert np.array_equal(O.decompress_frame(np.frombuffer(out[k], np.uint8)), np.frombuffer(xs[k], np.uint8))
