@@ -26,6 +26,10 @@ __device__ __forceinline__ void st8u(uint8_t *p, uint64_t v) { ((hb_u64u *)p)->v
 __device__ __forceinline__ uint32_t ld4u(const uint8_t *p) { return ((const hb_u32u *)p)->v; }
 __device__ __forceinline__ void st4u(uint8_t *p, uint32_t v) { ((hb_u32u *)p)->v = v; }
 
+// wave-wide predicate mask straight from the compare (HIP's __ballot() first materialises the predicate as 0/1:
+// v_cndmask + v_cmp per call)
+#define hb_ballot(pred) __builtin_amdgcn_ballot_w64(pred)
+
 // all lanes of the wave have finished their LDS traffic up to here, and the compiler may not
 // move LDS accesses across this point (single-wave producer/consumer through LDS).
 __device__ __forceinline__ void wave_sync() {

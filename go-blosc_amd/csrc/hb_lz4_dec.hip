@@ -82,7 +82,7 @@ __device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged,
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const bool ff = (v[k].x & v[k].y & v[k].z & v[k].w) == 0xFFFFFFFFu;
-                    const unsigned long long bad = __ballot(!ff);
+                    const unsigned long long bad = hb_ballot(!ff);
                     if (allff) {
                         if (bad) { adv += 16u * (uint32_t)__builtin_ctzll(bad); allff = false; }
                         else adv += 1024u;
@@ -96,7 +96,7 @@ __device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged,
         const uint32_t i = si + lane;
         uint32_t b = 0;                                   // out of range reads as a terminator
         if (i < slen) b = (i < staged) ? in[i] : g[i];
-        const unsigned long long stop = __ballot(b != 255u);
+        const unsigned long long stop = hb_ballot(b != 255u);
         if (stop == 0) { sum += 255u * 64u; si += 64; if (sum > 0xFFFFFFF0ull) return false; continue; }
         const int f = __builtin_ctzll(stop);
         if (si + (uint32_t)f >= slen) return false;
@@ -196,7 +196,7 @@ __device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh,
         const uint32_t nxt = offpos + 2u + nbm;
         // follow the real token chain through the window: one bit-set + one readlane per token; a
         // "complex" lane ends the walk (its successor is >= 64)
-        const unsigned long long cmask = __ballot(cplx);
+        const unsigned long long cmask = hb_ballot(cplx);
         unsigned long long tmask = 0;
         uint32_t cur;
         {
@@ -239,7 +239,7 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, con
         const uint32_t dpos = di + incl - olen;
         uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         unsigned long long amask = cntb >= 64u ? ~0ull : ((1ull << cntb) - 1ull);
-        const unsigned long long om = __ballot(olen != 0u && dpos + olen > outlen);
+        const unsigned long long om = hb_ballot(olen != 0u && dpos + olen > outlen);
         if (om) {                                        // this sequence passes the end of the unit: slow path from its token
             const int jx = __builtin_ctzll(om);
             amask &= (1ull << jx) - 1ull;
@@ -249,10 +249,10 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, con
         }
         const bool istok = (amask >> lane) & 1ull;
         // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
-        if (__ballot(istok && (offv == 0u || offv > dpos + lit + hist))) { ok = false; break; }
+        if (hb_ballot(istok && (offv == 0u || offv > dpos + lit + hist))) { ok = false; break; }
         // literals: short runs by their own lane, long runs by the whole wave
         if (istok && lit <= DLITCAP) lds_copy_exact(s_out + dpos, in + lsrc, lit);
-        unsigned long long lm = __ballot(istok && lit > DLITCAP);
+        unsigned long long lm = hb_ballot(istok && lit > DLITCAP);
         while (lm) {
             const int l = __builtin_ctzll(lm);
             const uint32_t sp = __builtin_amdgcn_readlane(lsrc, l), dp = __builtin_amdgcn_readlane(dpos, l);
@@ -286,7 +286,7 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, con
             const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP &&
                                (srcend <= (int)X || below == 0ull || src0 >= (int)pe);
             if (ready) lds_match_lane(s_out, mdv, offv, mlen);
-            pend &= ~__ballot(ready);
+            pend &= ~hb_ballot(ready);
         }
         di += total;
         if (rewound) { nq = 0; break; }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                     s_out[q++] = (uint8_t)((mcode - 15u) - 255u * (nbm - 1));
                 }
             }
-            unsigned long long lm = __ballot(act && lit > LITCAP);
+            unsigned long long lm = hb_ballot(act && lit > LITCAP);
             while (lm) {                                   // long literal runs: the whole wave copies
                 const int l = __builtin_ctzll(lm);
                 const uint32_t s = __builtin_amdgcn_readlane(prev, l), dq = __builtin_amdgcn_readlane(litdst, l);
@@ -253,14 +253,14 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             // the offset-1 candidate of a run needs no second read: its match is the rest of the run
             const uint32_t xa = hit ? (cv4 ^ v4) : (b4 ^ v4), xb = hit ? (cv8 ^ v8) : (b4 ^ v8);
             cand = hit ? cand : (uint32_t)p - 1u;
-            unsigned long long mask = __ballot(ism);
+            unsigned long long mask = hb_ballot(ism);
             if (mask) {
                 // every lane extends its own match to at most 12 bytes (branch-free)
                 uint32_t ml = xa ? 4u + ((uint32_t)__builtin_ctz(xa) >> 3) : (xb ? 8u + ((uint32_t)__builtin_ctz(xb) >> 3) : 12u);
                 bool lng = ism && (xa | xb) == 0u;
                 const uint32_t maxl = (uint32_t)(mend_max - p);
                 if (ml >= maxl) { ml = maxl; lng = false; }
-                const unsigned long long lmask = __ballot(lng);
+                const unsigned long long lmask = hb_ballot(lng);
                 // greedy left-to-right selection: scalar walk over the hit mask
                 unsigned long long sel = 0;
                 int last_end = anchor;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                             int eq = x ? (__builtin_ctz(x) >> 3) : 4;
                             const int avail = maxl - i;
                             if (avail < eq) eq = avail > 0 ? avail : 0;
-                            const unsigned long long part = __ballot(eq != 4);
+                            const unsigned long long part = hb_ballot(eq != 4);
                             if (part) {
                                 const int f = __builtin_ctzll(part);
                                 mlj += 4 * f + (int)__builtin_amdgcn_readlane((uint32_t)eq, f);
