@@ -395,11 +395,12 @@ int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int 
                           int typesize, unsigned opts, int device) {
     if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271 (before anything else)
     if (!src || !dst) return HB_ERR_BAD_ARG;
-    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;                 // blosc.go:322-325
+    if (codec != HB_LZ4 && !(codec == HB_ZSTD && hb_zstd_available())) return HB_ERR_INVALID_CODEC;   // blosc.go:322-325
     // the header fields are uint32 (blosc.go:159-161); the reference truncates silently (:363-365), this does not
     if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
     int rc = select_device(device);
     if (rc) return rc;
+    if (codec == HB_ZSTD) return hb_zstd_compress_frame(src, n, dst, cap, level, shuffle, typesize, opts, device);
     Scratch sc(device);
     const size_t fb = hb_frame_bound(n), wb = hb_compress_frame_workspace(n);
     uint8_t *d_src = sc.get(n + 16), *d_frame = sc.get(fb + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
@@ -424,6 +425,13 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     int rc = hb_parse_header(frame, n, &h);
     if (rc) return rc;
     if ((size_t)h.cbytes > n || h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;
+    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec == HB_ZSTD) {           // config 5: host codec, device un-filter (hb_zstd.hip)
+        if (!hb_zstd_available()) return HB_ERR_INVALID_CODEC;
+        rc = select_device(device);
+        if (rc) return rc;
+        g_last_flags = 0;
+        return hb_zstd_decompress_frame(frame, h, dst, cap, typesize_override, device);
+    }
     if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;
     rc = select_device(device);
     if (rc) return rc;

@@ -44,6 +44,12 @@ struct hb_dec_args {
     uint8_t *staged;                     // fused_bitunshuffle4: where the serial fallback puts the still-filtered bytes
 };
 
+// hb_zstd.hip: host ZSTD behind the device filter (BASELINE.json config 5)
+bool hb_zstd_available();
+int64_t hb_zstd_compress_frame(const void *src, size_t n, void *dst, size_t cap, int level, int shuffle, int typesize,
+                               unsigned opts, int device);
+int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *dst, size_t cap, int typesize_override, int device);
+
 size_t hb_lz4_enc_workspace(size_t n);
 size_t hb_lz4_dec_workspace(size_t n_out);
 size_t hb_lz4_index_bound(size_t n);

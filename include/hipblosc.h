@@ -132,7 +132,11 @@ size_t  hb_index_bound(size_t n);   /* bytes of restart index for an n-byte bloc
 int     hb_parse_header(const void *frame, size_t n, hb_header *out);                 /* ParseHeader, blosc.go:165-185 */
 void    hb_header_bytes(const hb_header *h, void *out16);                             /* (*Header).Bytes, blosc.go:188-198 */
 size_t  hb_frame_bound(size_t n);                                                     /* 16 + lz4 bound + index trailer */
-/* returns bytes written to dst (cbytes, plus the trailer when HB_OPT_INDEX_TRAILER) */
+/* returns bytes written to dst (cbytes, plus the trailer when HB_OPT_INDEX_TRAILER).
+ * codec HB_LZ4: everything on the device.  codec HB_ZSTD (BASELINE.json config 5): the filter runs on the device, ZSTD stays
+ * a host codec as in the reference (codec.go:173-222) -- one zstd frame per 16 MiB slice, compressed by host threads while
+ * the next slices are still being copied back; the concatenation decodes with zstd.Decoder.DecodeAll.  Needs libzstd.so.1
+ * at run time (else HB_ERR_INVALID_CODEC); host-pointer entry points only. */
 int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap,
                           int codec, int level, int shuffle, int typesize,
                           unsigned opts, int device);

@@ -342,3 +342,41 @@ def test_concurrent_calls_from_many_threads(hb, O):
     assert not errs, errs
     for k in range(6):
         assert np.array_equal(O.decompress_frame(np.frombuffer(out[k], np.uint8)), np.frombuffer(xs[k], np.uint8))
+
+
+def test_config5_device_shuffle_host_zstd(hb, O):
+    # BASELINE.json config 5 (scaled): Shuffle1 + ZSTD level 3; filter on the device, zstd on host threads.
+    # Oracle for the codec: libzstd itself (ZSTD_decompress decodes concatenated frames like DecodeAll), then the
+    # restated unshuffle.
+    zs = None
+    for p in ("/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"):
+        if os.path.exists(p):
+            zs = ctypes.CDLL(p)
+            break
+    if zs is None:
+        pytest.skip("libzstd not in this image")
+    zs.ZSTD_decompress.restype = ctypes.c_size_t
+    zs.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    for x, shuffle, ts in [(O.synth(O.D_F32, (40 << 20) // 4 + 3), hb.Shuffle1, 4),          # 3 slices, ragged
+                           (O.synth(O.D_I32, 100000), hb.BitShuffle, 4),
+                           (np.random.default_rng(3).integers(0, 256, 300000, dtype=np.uint8), hb.Shuffle1, 4),   # memcpy
+                           (O.synth(O.D_F64, 50000), hb.NoShuffle, 8)]:
+        f = hb.Compress(x.tobytes(), hb.ZSTD, 3, shuffle, ts)
+        h = hb.ParseHeader(f)
+        assert (h.Version, h.VersionLZ, h.TypeSize, h.NBytesOrig, h.NBytesComp) == (2, hb.ZSTD, ts, x.size, len(f))
+        payload = f[16:]
+        if h.IsMemcpy():
+            filt = np.frombuffer(payload, np.uint8)
+        else:
+            out = ctypes.create_string_buffer(x.size)
+            r = zs.ZSTD_decompress(out, x.size, payload, len(payload))
+            assert r == x.size
+            filt = np.frombuffer(out.raw, np.uint8)
+        op = {hb.Shuffle1: O.OP_UNSHUFFLE, hb.BitShuffle: O.OP_BITUNSHUFFLE}.get(shuffle)
+        back = filt if op is None or ts <= 1 else O.filter(op, filt, ts)
+        assert np.array_equal(back, x), "libzstd + restated unshuffle cannot reproduce the input"
+        assert hb.Decompress(f) == x.tobytes()
+    with pytest.raises(hb.ErrDecompressionFailed):
+        g = bytearray(hb.Compress(O.synth(O.D_F32, 20000).tobytes(), hb.ZSTD, 3, hb.Shuffle1, 4))
+        g[30] ^= 0xFF; g[40] ^= 0xFF
+        hb.Decompress(bytes(g))
