@@ -140,14 +140,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
-#define QCAP 128            // sequence queue slots (flushed 64 at a time)
+#define QCAP 80             // sequence queue slots: flushed once 64 are queued, and a step adds at most 16 (matches are >= 4 bytes)
+#define SOUT 1280u          // bytes of record staging per wave: drained to the record in HBM after every flush (LDS per wave
+                            // sets the number of resident waves, and the matcher is latency-bound: time ~ 1 / waves)
 
 // One chunk, one wavefront.  The chunk image is in LDS (byte i of the chunk at s_data[sh + i]); s_out / s_tab /
 // s_q are this wave's scratch; the record goes to `rec`, the summary to *dsc.  with_trailing: also append the
 // un-matched tail of the chunk to the record (fused filter: there is no filtered buffer in HBM for k_stitch to
 // take literals from; a chunk without any match then stores its whole image).
 __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_t sh, const int len,
-                                            uint8_t *s_out, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */,
+                                            uint8_t *s_out /* SOUT + 16 */, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */,
                                             ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const int lane) {
     {
         {
@@ -156,17 +158,42 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
         }
         wave_sync();
 
-        int pos = 0, anchor = 0, o = 0, nq = 0, nseq = 0, miss = 0;
+        int pos = 0, anchor = 0, nq = 0, nseq = 0, miss = 0;
+        uint32_t rec_done = 0, opend = 0;                 // record bytes already in HBM (multiple of 16) / pending in s_out
         uint32_t batch_anchor = 0, lead = 0, mcode0 = 0;
         const int mstart_max = len - 12;                  // last position a match may start at
         const int mend_max = len - 5;                     // matches end at or before this
         const uint8_t *data = s_data + sh;
 #define RD4(x) lds_read4(s_data, sh + (uint32_t)(x))
 
-        // emit the first min(nq, 64) queued sequences, one per lane
+        // write the complete 16-byte blocks of s_out to the record and keep the tail (all: the tail too, padded)
+        auto drain = [&](const bool all) __attribute__((always_inline)) {
+            wave_sync();
+            const uint32_t full = all ? ((opend + 15u) & ~15u) : (opend & ~15u);
+            if (full) {
+                for (uint32_t i = lane * 16u; i < full; i += 1024u) *(u32x4 *)(rec + rec_done + i) = *(const u32x4 *)(s_out + i);
+                if (!all && lane == 0) { const u32x4 t = *(const u32x4 *)(s_out + full); *(u32x4 *)s_out = t; }
+                rec_done += full;
+                opend = all ? 0u : opend - full;
+                wave_sync();
+            }
+        };
+        // wave copy of `cnt` chunk bytes from position `from` into the record, through s_out
+        auto stream_literals = [&](uint32_t from, uint32_t cnt) __attribute__((always_inline)) {
+            while (cnt) {
+                const uint32_t piece = cnt < SOUT - opend ? cnt : SOUT - opend;
+                for (uint32_t k = lane * 4u; k < piece; k += 256u) {
+                    if (k + 4u <= piece) ((hb_u32u *)(s_out + opend + k))->v = RD4(from + k);
+                    else for (uint32_t r = k; r < piece; r++) s_out[opend + r] = data[from + r];
+                }
+                opend += piece; from += piece; cnt -= piece;
+                drain(false);
+            }
+        };
+
+        // emit queued sequences, one per lane: as many of the first min(nq, 64) as fit into s_out
         auto flush = [&]() __attribute__((always_inline)) {
-            const int cntb = nq < 64 ? nq : 64;
-            const bool act = lane < cntb;
+            const int take = nq < 64 ? nq : 64;
             const uint2 e = s_q[lane];
             const uint32_t q_mp = e.x & 0xFFFFu, q_ml = e.x >> 16, q_off = e.y;
             const uint32_t end = q_mp + q_ml;
@@ -175,51 +202,83 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t lit = q_mp - prev, mcode = q_ml - 4u;
             const bool first = (nseq == 0) && lane == 0;  // sequence 0 of the chunk: token comes from k_stitch
             const uint32_t nbl = first ? 0u : lz4_ext_bytes(lit), nbm = lz4_ext_bytes(mcode);
-            const uint32_t size = act ? ((first ? 0u : 1u) + nbl + lit + 2u + nbm) : 0u;
+            const uint32_t size = lane < take ? ((first ? 0u : 1u) + nbl + lit + 2u + nbm) : 0u;
             const uint32_t incl = wave_incl_scan(size, lane);
-            uint32_t q = (uint32_t)o + incl - size;
-            uint32_t litdst = 0;
-            if (act) {
-                if (!first) {
-                    s_out[q++] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
-                    if (nbl) {
-                        for (uint32_t k = 0; k + 1 < nbl; k++) s_out[q++] = 255;
-                        s_out[q++] = (uint8_t)((lit - 15u) - 255u * (nbl - 1));
-                    }
-                }
-                litdst = q;
-                if (lit <= LITCAP) lds_copy_exact(s_out + q, data + prev, lit);
-                q += lit;
-                ((hb_u16u *)(s_out + q))->v = (uint16_t)q_off;
-                q += 2;
-                if (nbm) {
-                    for (uint32_t k = 0; k + 1 < nbm; k++) s_out[q++] = 255;
-                    s_out[q++] = (uint8_t)((mcode - 15u) - 255u * (nbm - 1));
-                }
-            }
-            unsigned long long lm = hb_ballot(act && lit > LITCAP);
-            while (lm) {                                   // long literal runs: the whole wave copies
-                const int l = __builtin_ctzll(lm);
-                const uint32_t s = __builtin_amdgcn_readlane(prev, l), dq = __builtin_amdgcn_readlane(litdst, l);
-                const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
-                for (uint32_t k = lane * 4u; k < ln; k += 256u) {
-                    if (k + 4u <= ln) ((hb_u32u *)(s_out + dq + k))->v = ((const hb_u32u *)(data + s + k))->v;
-                    else for (uint32_t r = k; r < ln; r++) s_out[dq + r] = data[s + r];
-                }
-                lm &= lm - 1;
-            }
+            int cnt = __builtin_popcountll(hb_ballot(lane < take && incl <= SOUT - opend));
             if (nseq == 0) {
                 lead = __builtin_amdgcn_readlane(lit, 0);
                 const uint32_t m0 = __builtin_amdgcn_readlane(mcode, 0);
                 mcode0 = m0 < 15u ? m0 : 15u;
             }
-            o += (int)__builtin_amdgcn_readlane(incl, 63);
-            batch_anchor = __builtin_amdgcn_readlane(end, cntb - 1);
-            nseq += cntb;
-            // keep what is queued beyond the 64 just emitted
-            const uint2 rest = s_q[64 + lane];
-            nq -= cntb;
-            if (lane < nq) s_q[lane] = rest;
+            if (cnt == 0) {
+                // the first queued sequence alone is larger than the staging buffer (a literal run of > 1 KiB):
+                // header, then the literals in pieces, then offset + match extension
+                cnt = 1;
+                if (lane == 0) {
+                    uint32_t q = opend;
+                    if (!first) {
+                        s_out[q++] = (uint8_t)((15u << 4) | (mcode < 15u ? mcode : 15u));
+                        for (uint32_t k = 0; k + 1 < nbl; k++) s_out[q++] = 255;
+                        s_out[q++] = (uint8_t)((lit - 15u) - 255u * (nbl - 1));
+                    }
+                }
+                opend += (uint32_t)__builtin_amdgcn_readlane((first ? 0u : 1u) + nbl, 0);
+                wave_sync();
+                stream_literals(__builtin_amdgcn_readlane(prev, 0), __builtin_amdgcn_readlane(lit, 0));
+                if (lane == 0) {
+                    uint32_t q = opend;
+                    ((hb_u16u *)(s_out + q))->v = (uint16_t)q_off;
+                    q += 2;
+                    if (nbm) {
+                        for (uint32_t k = 0; k + 1 < nbm; k++) s_out[q++] = 255;
+                        s_out[q++] = (uint8_t)((mcode - 15u) - 255u * (nbm - 1));
+                    }
+                }
+                opend += 2u + (uint32_t)__builtin_amdgcn_readlane(nbm, 0);
+            } else {
+                const bool act = lane < cnt;
+                uint32_t q = opend + incl - size;
+                uint32_t litdst = 0;
+                if (act) {
+                    if (!first) {
+                        s_out[q++] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
+                        if (nbl) {
+                            for (uint32_t k = 0; k + 1 < nbl; k++) s_out[q++] = 255;
+                            s_out[q++] = (uint8_t)((lit - 15u) - 255u * (nbl - 1));
+                        }
+                    }
+                    litdst = q;
+                    if (lit <= LITCAP) lds_copy_exact(s_out + q, data + prev, lit);
+                    q += lit;
+                    ((hb_u16u *)(s_out + q))->v = (uint16_t)q_off;
+                    q += 2;
+                    if (nbm) {
+                        for (uint32_t k = 0; k + 1 < nbm; k++) s_out[q++] = 255;
+                        s_out[q++] = (uint8_t)((mcode - 15u) - 255u * (nbm - 1));
+                    }
+                }
+                unsigned long long lm = hb_ballot(act && lit > LITCAP);
+                while (lm) {                                   // long literal runs: the whole wave copies
+                    const int l = __builtin_ctzll(lm);
+                    const uint32_t s = __builtin_amdgcn_readlane(prev, l), dq = __builtin_amdgcn_readlane(litdst, l);
+                    const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
+                    for (uint32_t k = lane * 4u; k < ln; k += 256u) {
+                        if (k + 4u <= ln) ((hb_u32u *)(s_out + dq + k))->v = ((const hb_u32u *)(data + s + k))->v;
+                        else for (uint32_t r = k; r < ln; r++) s_out[dq + r] = data[s + r];
+                    }
+                    lm &= lm - 1;
+                }
+                opend += (uint32_t)__builtin_amdgcn_readlane(incl, cnt - 1);
+            }
+            batch_anchor = __builtin_amdgcn_readlane(end, cnt - 1);
+            nseq += cnt;
+            // keep what is queued beyond the sequences just emitted
+            const uint32_t i0 = (uint32_t)(lane + cnt), i1 = i0 + 64u;
+            const uint2 r0 = s_q[i0 < QCAP ? i0 : 0], r1 = s_q[i1 < QCAP ? i1 : 0];
+            drain(false);                                      // (its wave_sync also orders the queue reads before the writes)
+            nq -= cnt;
+            if (lane < nq) s_q[lane] = r0;
+            if (lane + 64 < nq) s_q[lane + 64] = r1;
         };
 
         while (pos <= mstart_max) {
@@ -319,7 +378,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 }
                 nq += __builtin_popcountll(sel);
                 anchor = last_end;
-                if (nq >= 64) flush();
+                while (nq >= 64) flush();
                 miss = 0;
             } else {
                 miss++;
@@ -328,23 +387,18 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             pos = anchor > nxt ? anchor : nxt;
         }
         while (nq > 0) flush();
-        wave_sync();
-        int total = o;
+        const uint32_t enc = rec_done + opend;             // record bytes without the trailing literals
         if (with_trailing) {
             if (nseq == 0 && sh == 0) {            // no match at all: the record is the image itself
                 for (int i = lane * 16; i < len; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_data + i);
-                total = 0;
             } else {
-                const int trail = len - anchor;
-                for (int i = lane; i < trail; i += 64) s_out[o + i] = data[anchor + i];
-                total = o + trail;
-                wave_sync();
+                stream_literals((uint32_t)anchor, (uint32_t)(len - anchor));
             }
         }
-        for (int i = lane * 16; i < total; i += 64 * 16) *(u32x4 *)(rec + i) = *(const u32x4 *)(s_out + i);
+        drain(true);
         if (lane == 0) {
             ChunkDesc d;
-            d.lead = nseq ? lead : 0u; d.enc_len = nseq ? (uint32_t)o : 0u;
+            d.lead = nseq ? lead : 0u; d.enc_len = nseq ? enc : 0u;
             d.last_end = nseq ? (uint32_t)anchor : 0u; d.mcode0 = mcode0;
             *dsc = d;
         }
@@ -360,8 +414,8 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
                                               uint32_t nchunks, int bits4) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 96];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
     const int lane = threadIdx.x;
@@ -396,8 +450,8 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 template <int TS>
 __global__ __launch_bounds__(64) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
                                                     uint8_t *__restrict__ records, uint32_t nblk) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 128];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 96];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
     const int lane = threadIdx.x;
