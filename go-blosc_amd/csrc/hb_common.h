@@ -38,6 +38,23 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// value of lane-1 (lane 0 gets `first`): one DPP move (wave_shr:1), no LDS round trip like __shfl_up
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// inclusive prefix sum over the 64 lanes with DPP adds: row_shr 1/2/4/8 inside the rows of 16, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3 (gfx9 DPP controls)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return v;
+}
+
 // 4x4 byte transpose: in e[i] = bytes of row i; out p[j] = {e0.bj, e1.bj, e2.bj, e3.bj}.  Involution.
 __device__ __forceinline__ void transpose4x4(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3,
                                              uint32_t &p0, uint32_t &p1, uint32_t &p2, uint32_t &p3) {

@@ -142,14 +142,7 @@ __device__ __forceinline__ void lds_match_lane(uint8_t *out, uint32_t md, uint32
     }
     for (uint32_t k = 0; k < len; k++) out[md + k] = out[md - off + k];   // offsets 2..7: byte by byte
 }
-__device__ __forceinline__ uint32_t dec_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t dec_incl_scan(uint32_t v, int lane) { (void)lane; return wave_incl_scan_dpp(v); }
 
 // copy a match inside the LDS image of the chunk; all arguments wave-uniform, source fully produced
 __device__ __forceinline__ void dec_match_copy(uint8_t *s_out, uint32_t md, uint32_t off, uint32_t ml, int lane) {

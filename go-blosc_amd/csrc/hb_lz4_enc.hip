@@ -131,15 +131,6 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
     if (len & 1u) d[k] = s[k];
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
 #define QCAP 80             // sequence queue slots: flushed once 64 are queued, and a step adds at most 16 (matches are >= 4 bytes)
 #define SOUT 1280u          // bytes of record staging per wave: drained to the record in HBM after every flush (LDS per wave
                             // sets the number of resident waves, and the matcher is latency-bound: time ~ 1 / waves)
@@ -197,13 +188,12 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint2 e = s_q[lane];
             const uint32_t q_mp = e.x & 0xFFFFu, q_ml = e.x >> 16, q_off = e.y;
             const uint32_t end = q_mp + q_ml;
-            uint32_t prev = __shfl_up(end, 1);
-            if (lane == 0) prev = batch_anchor;
+            const uint32_t prev = wave_shr1(end, batch_anchor);
             const uint32_t lit = q_mp - prev, mcode = q_ml - 4u;
             const bool first = (nseq == 0) && lane == 0;  // sequence 0 of the chunk: token comes from k_stitch
             const uint32_t nbl = first ? 0u : lz4_ext_bytes(lit), nbm = lz4_ext_bytes(mcode);
             const uint32_t size = lane < take ? ((first ? 0u : 1u) + nbl + lit + 2u + nbm) : 0u;
-            const uint32_t incl = wave_incl_scan(size, lane);
+            const uint32_t incl = wave_incl_scan_dpp(size);
             int cnt = __builtin_popcountll(hb_ballot(lane < take && incl <= SOUT - opend));
             if (nseq == 0) {
                 lead = __builtin_amdgcn_readlane(lit, 0);
@@ -293,8 +283,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t v8 = __builtin_amdgcn_alignbyte(p3, p2, ap & 3u);
             const bool valid = p <= mstart_max;
             // inside a run of equal 4-grams <=> data[p-1] == data[p] == ... == data[p+3]
-            uint32_t before = (uint32_t)__shfl_up((int)(v & 255u), 1);
-            if (lane == 0) before = prevb;
+            const uint32_t before = wave_shr1(v & 255u, prevb);
             const uint32_t b4 = (v & 255u) * 0x01010101u;
             const bool rle = valid && p >= 1 && v == b4 && before == (v & 255u);
             const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
