@@ -281,11 +281,17 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t v = __builtin_amdgcn_alignbyte(p1, p0, ap & 3u);
             const uint32_t v4 = __builtin_amdgcn_alignbyte(p2, p1, ap & 3u);
             const uint32_t v8 = __builtin_amdgcn_alignbyte(p3, p2, ap & 3u);
+            // predicates are kept as wave masks (one v_cmp each, combined on the scalar side): a ballot of a compound
+            // bool would first be materialised per lane
             const bool valid = p <= mstart_max;
             // inside a run of equal 4-grams <=> data[p-1] == data[p] == ... == data[p+3]
-            const uint32_t before = wave_shr1(v & 255u, prevb);
-            const uint32_t b4 = (v & 255u) * 0x01010101u;
-            const bool rle = valid && p >= 1 && v == b4 && before == (v & 255u);
+            const uint32_t vb = v & 255u;
+            const uint32_t before = wave_shr1(vb, prevb);
+            const uint32_t b4 = vb * 0x01010101u;
+            const unsigned long long m_first = pos > 0 ? ~0ull : ~1ull;            // p >= 1
+            const unsigned long long m_eqprev = hb_ballot(before == vb);           // bit l: data[pos+l] == data[pos+l-1]
+            const unsigned long long m_rle = hb_ballot(valid) & hb_ballot(v == b4) & m_eqprev & m_first;
+            const bool rle = valid && (pos > 0 || lane > 0) && v == b4 && before == vb;
             const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
             uint32_t cand = s_tab[h];
             if (valid && !rle) s_tab[h] = (uint16_t)p;
@@ -296,38 +302,58 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t cv = __builtin_amdgcn_alignbyte(c1, c0, ac & 3u);
             const uint32_t cv4 = __builtin_amdgcn_alignbyte(c2, c1, ac & 3u);
             const uint32_t cv8 = __builtin_amdgcn_alignbyte(c3, c2, ac & 3u);
+            const unsigned long long m_hit = hb_ballot(valid) & hb_ballot((int)cand < p) & hb_ballot(cv == v);
             const bool hit = valid && (int)cand < p && cv == v;
-            const bool ism = hit || rle;
             // the offset-1 candidate of a run needs no second read: its match is the rest of the run
             const uint32_t xa = hit ? (cv4 ^ v4) : (b4 ^ v4), xb = hit ? (cv8 ^ v8) : (b4 ^ v8);
             cand = hit ? cand : (uint32_t)p - 1u;
-            unsigned long long mask = hb_ballot(ism);
+            unsigned long long mask = m_hit | m_rle;
             if (mask) {
-                // every lane extends its own match to at most 12 bytes (branch-free)
-                uint32_t ml = xa ? 4u + ((uint32_t)__builtin_ctz(xa) >> 3) : (xb ? 8u + ((uint32_t)__builtin_ctz(xb) >> 3) : 12u);
-                bool lng = ism && (xa | xb) == 0u;
+                // every lane extends its own match to at most 12 bytes, branch-free: v_ffbl_b32 gives -1 for 0, so the
+                // first differing bit of the 8 bytes is min(ffbl(xa), 32 + min(ffbl(xb), 32))
+                uint32_t fa, fb;
+                asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(xa));
+                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(xb));
+                const uint32_t fbit = min(fa, min(fb, 32u) + 32u);
+                uint32_t ml = 4u + (fbit >> 3);
                 const uint32_t maxl = (uint32_t)(mend_max - p);
-                if (ml >= maxl) { ml = maxl; lng = false; }
-                const unsigned long long lmask = hb_ballot(lng);
+                unsigned long long lmask = mask & hb_ballot(fbit == 64u) & hb_ballot(ml < maxl);
+                ml = min(ml, maxl);
+                if (lmask & m_rle & ~m_hit) {
+                    // a run: the offset-1 match is the rest of the run, and the wave already knows where runs end as far
+                    // as this window goes -- only a run that leaves the window needs the cooperative extension
+                    const uint32_t run = (uint32_t)__builtin_ctzll(~(m_eqprev >> lane));
+                    const bool inwin = !hit && fbit == 64u && (uint32_t)lane + run < 64u;
+                    if (inwin) ml = min(run, maxl);
+                    lmask &= ~(hb_ballot(inwin) & m_rle);
+                }
                 // greedy left-to-right selection: scalar walk over the hit mask
                 unsigned long long sel = 0;
                 int last_end = anchor;
                 if (lmask == 0) {
                     // all lengths known: every hit lane computes its successor (first hit at or after the end of
-                    // its match, 64 = leaves the step) and the walk is one bit-set + one readlane per sequence
+                    // its match; the last one points at itself) and the walk is one bit-set + one readlane per
+                    // sequence, unrolled by 4 (setting the bit of the last lane again is harmless)
                     const uint32_t x = (uint32_t)lane + ml;
-                    uint32_t succ = 64;
+                    uint32_t succ = (uint32_t)lane;
                     if (x < 64u) {
                         const unsigned long long m = mask >> x;
                         if (m) succ = x + (uint32_t)__builtin_ctzll(m);
                     }
                     uint32_t j = (uint32_t)__builtin_ctzll(mask);
-                    uint32_t lastj = j;
-                    do {
+                    uint32_t lastj;
+                    for (;;) {
                         asm volatile("s_bitset1_b64 %0, %1" : "+s"(sel) : "s"(j));
-                        lastj = j;
-                        j = __builtin_amdgcn_readlane(succ, (int)j);
-                    } while (j < 64u);
+                        const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                        asm volatile("s_bitset1_b64 %0, %1" : "+s"(sel) : "s"(j1));
+                        const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                        asm volatile("s_bitset1_b64 %0, %1" : "+s"(sel) : "s"(j2));
+                        const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                        asm volatile("s_bitset1_b64 %0, %1" : "+s"(sel) : "s"(j3));
+                        j = __builtin_amdgcn_readlane(succ, (int)j3);
+                        lastj = j3;
+                        if (j == j3) break;
+                    }
                     last_end = pos + (int)lastj + (int)__builtin_amdgcn_readlane(ml, (int)lastj);
                     mask = 0;
                 }
