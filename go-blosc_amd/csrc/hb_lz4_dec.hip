@@ -194,12 +194,21 @@ __device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh,
         uint32_t cur;
         {
             const uint32_t nrel = cplx ? 64u : nxt - base;
-            uint32_t j = 0;
-            do {
+            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;   // the last token of the window points at itself
+            uint32_t j = 0, lastj;
+            for (;;) {                                       // unrolled by 4: setting the last bit again is harmless
                 asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
-                j = __builtin_amdgcn_readlane(nrel, (int)j);
-            } while (j < 64u);
-            cur = base + j;
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
             const unsigned long long cm = tmask & cmask;  // at most the last visited lane
             if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
         }
