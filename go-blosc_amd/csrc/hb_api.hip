@@ -351,6 +351,17 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
     hb_header h;
     int rc = hb_parse_header(hb, HB_HEADER_SIZE, &h);                 // blosc.go:379-382
     if (rc) return rc;
+    return hb_decompress_frame_dev_hdr(h, d_frame, n, d_dst, cap, typesize_override, d_work, work_bytes, d_result, stream);
+}
+
+}  // extern "C"
+
+// the same with the header already parsed (host callers have the frame in host memory: no read-back, no sync)
+int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t n, void *d_dst, size_t cap, int typesize_override,
+                                void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;
     if ((size_t)h.cbytes > n) return HB_ERR_INVALID_DATA;             // blosc.go:385-387
     if (h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;        // blosc.go:388-390
     if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;  // :403-407
@@ -390,6 +401,8 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
     }
     return HB_OK;
 }
+
+extern "C" {
 
 int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int codec, int level, int shuffle,
                           int typesize, unsigned opts, int device) {
@@ -441,7 +454,7 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     uint8_t *d_frame = sc.get(n + 64), *d_dst = sc.get((size_t)h.nbytes + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
     if (!d_frame || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
     HB_HIP_TRY(hipMemcpy(d_frame, frame, n, hipMemcpyHostToDevice));
-    rc = hb_decompress_frame_dev(d_frame, n, d_dst, h.nbytes, typesize_override, d_work, wb, (hb_result *)d_res, nullptr);
+    rc = hb_decompress_frame_dev_hdr(h, d_frame, n, d_dst, h.nbytes, typesize_override, d_work, wb, (hb_result *)d_res, nullptr);
     if (rc) return rc;
     hb_result r;
     HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));

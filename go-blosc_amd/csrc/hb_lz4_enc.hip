@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256) void k_scan(const Agg *__restrict__ tile_agg, 
             if (has_index && !use_memcpy) {
                 plan->index_off = ((uint64_t)cbytes + 7) & ~7ull;
                 total = plan->index_off + HB_IDX_HDR_BYTES + (uint64_t)HB_IDX_ENTRY * (nchunks + 1);
+                for (uint64_t i = cbytes; i < plan->index_off; i++) dst[i] = 0;   // pad: frames are deterministic byte for byte
             }
             result->total_bytes = total;
         } else {

@@ -1,0 +1,173 @@
+// hb_queue.hip — pipelined host API (include/hipblosc.h "hb_queue_*").
+//
+// One slot = one frame in flight: its own stream, device buffers (input, frame / output, workspace) and a pinned
+// hb_result.  Submitting enqueues  H2D -> kernels -> result D2H  on the slot's stream and returns; waiting synchronises
+// with that stream, reads how many bytes came out, and downloads exactly those.  With `depth` slots the upload of frame
+// k+1 overlaps the kernels of frame k and the download of frame k-1 (the two PCIe directions and the compute queue are
+// independent engines), which is what the one-call API of hb_api.hip cannot do.
+#include "hb_common.h"
+#include "hb_lz4.h"
+
+#include <vector>
+#include <new>
+
+extern "C" {
+size_t hb_frame_bound(size_t n);
+size_t hb_compress_frame_workspace(size_t n);
+size_t hb_decompress_frame_workspace(size_t n_out);
+int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap, int codec, int level, int shuffle,
+                          int typesize, unsigned opts, void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+}
+
+namespace {
+enum SlotState { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_DONE = 2 };
+struct Slot {
+    hipStream_t stream = nullptr;
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_work = nullptr;
+    hb_result *d_res = nullptr;          // device
+    hb_result *h_res = nullptr;          // pinned
+    int state = SLOT_FREE;
+    int64_t ticket = -1;
+    int64_t rc = 0;                      // SLOT_DONE: what wait() returns
+    bool compress = false;
+    void *dst = nullptr; size_t cap = 0; unsigned opts = 0;
+};
+}  // namespace
+
+struct hb_queue {
+    int device = 0;
+    size_t max_n = 0, in_bytes = 0, out_bytes = 0, work_bytes = 0;
+    std::vector<Slot> slots;
+    int64_t next_ticket = 0;
+};
+
+namespace {
+
+void free_slot(Slot &s) {
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.d_work) (void)hipFree(s.d_work);
+    if (s.d_res) (void)hipFree(s.d_res);
+    if (s.h_res) (void)hipHostFree(s.h_res);
+    s = Slot();
+}
+
+// bring a busy slot to SLOT_DONE: wait for its kernels, download what they produced
+void finish(hb_queue *q, Slot &s) {
+    if (s.state != SLOT_BUSY) return;
+    s.state = SLOT_DONE;
+    if (hipSetDevice(q->device) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess) { s.rc = HB_ERR_HIP; return; }
+    const hb_result r = *s.h_res;
+    if (r.status) { s.rc = r.status; return; }
+    const size_t out = s.compress ? ((s.opts & HB_OPT_INDEX_TRAILER) ? r.total_bytes : r.bytes) : r.bytes;
+    if (out > s.cap) { s.rc = HB_ERR_SHORT_BUFFER; return; }
+    if (out) {
+        if (hipMemcpyAsync(s.dst, s.d_out, out, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
+            hipStreamSynchronize(s.stream) != hipSuccess) { s.rc = HB_ERR_HIP; return; }
+    }
+    s.rc = (int64_t)out;
+}
+
+Slot *take_slot(hb_queue *q, int64_t *ticket) {
+    *ticket = q->next_ticket++;
+    Slot &s = q->slots[(size_t)(*ticket % (int64_t)q->slots.size())];
+    finish(q, s);                        // all slots in flight: the oldest one is completed first (result kept)
+    return &s;
+}
+
+}  // namespace
+
+extern "C" {
+
+hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes) {
+    if (hb_init() != HB_OK || device < 0 || device >= hb_device_count() || depth < 1 || depth > 64 || max_nbytes == 0) return nullptr;
+    if (max_nbytes > 0xFFFFFFFFull - HB_HEADER_SIZE - max_nbytes / 255 - 64) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    hb_queue *q = new (std::nothrow) hb_queue();
+    if (!q) return nullptr;
+    q->device = device;
+    q->max_n = max_nbytes;
+    const size_t fb = hb_frame_bound(max_nbytes) + 64;
+    q->in_bytes = fb;                                       // compress: the input (<= max_n); decompress: a frame (<= bound)
+    q->out_bytes = fb;                                      // compress: the frame; decompress: the output (<= max_n)
+    q->work_bytes = hb_compress_frame_workspace(max_nbytes);
+    if (hb_decompress_frame_workspace(max_nbytes) > q->work_bytes) q->work_bytes = hb_decompress_frame_workspace(max_nbytes);
+    q->slots.resize((size_t)depth);
+    bool ok = true;
+    for (auto &s : q->slots) {
+        ok = ok && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s.d_in, q->in_bytes) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s.d_out, q->out_bytes) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s.d_work, q->work_bytes) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s.d_res, sizeof(hb_result)) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&s.h_res, sizeof(hb_result), hipHostMallocDefault) == hipSuccess;
+        if (!ok) break;
+    }
+    if (!ok) { for (auto &s : q->slots) free_slot(s); delete q; return nullptr; }
+    return q;
+}
+
+void hb_queue_destroy(hb_queue *q) {
+    if (!q) return;
+    (void)hipSetDevice(q->device);
+    for (auto &s : q->slots) { finish(q, s); free_slot(s); }
+    delete q;
+}
+
+int64_t hb_queue_compress(hb_queue *q, const void *src, size_t n, void *dst, size_t cap, int codec, int level, int shuffle,
+                          int typesize, unsigned opts) {
+    if (!q) return HB_ERR_BAD_ARG;
+    if (n == 0) return HB_ERR_INVALID_DATA;                               // blosc.go:269-271
+    if (!src || !dst) return HB_ERR_BAD_ARG;
+    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;                     // blosc.go:322-325; the queue carries the device codec only
+    if (n > q->max_n) return HB_ERR_DATA_TOO_LARGE;
+    if (hipSetDevice(q->device) != hipSuccess) return HB_ERR_HIP;
+    int64_t ticket;
+    Slot *s = take_slot(q, &ticket);
+    s->state = SLOT_DONE; s->ticket = ticket; s->compress = true; s->dst = dst; s->cap = cap; s->opts = opts;
+    s->rc = HB_ERR_HIP;
+    if (hipMemcpyAsync(s->d_in, src, n, hipMemcpyHostToDevice, s->stream) != hipSuccess) return ticket;   // wait() reports it
+    const int rc = hb_compress_frame_dev(s->d_in, n, s->d_out, q->out_bytes, codec, level, shuffle, typesize, opts,
+                                         s->d_work, q->work_bytes, s->d_res, s->stream);
+    if (rc) { s->rc = rc; return ticket; }
+    if (hipMemcpyAsync(s->h_res, s->d_res, sizeof(hb_result), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return ticket;
+    s->state = SLOT_BUSY;
+    return ticket;
+}
+
+int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst, size_t cap, int typesize_override) {
+    if (!q) return HB_ERR_BAD_ARG;
+    if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;                 // blosc.go:297-299
+    if (!frame) return HB_ERR_BAD_ARG;
+    hb_header h;
+    int rc = hb_parse_header(frame, n, &h);                               // the frame is in host memory: no read-back
+    if (rc) return rc;
+    if ((size_t)h.cbytes > n || h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;           // blosc.go:385-390
+    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;
+    if ((size_t)h.nbytes > q->max_n || n > q->in_bytes) return HB_ERR_DATA_TOO_LARGE;
+    if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
+    if (hipSetDevice(q->device) != hipSuccess) return HB_ERR_HIP;
+    int64_t ticket;
+    Slot *s = take_slot(q, &ticket);
+    s->state = SLOT_DONE; s->ticket = ticket; s->compress = false; s->dst = dst; s->cap = cap; s->opts = 0;
+    s->rc = HB_ERR_HIP;
+    if (hipMemcpyAsync(s->d_in, frame, n, hipMemcpyHostToDevice, s->stream) != hipSuccess) return ticket;
+    rc = hb_decompress_frame_dev_hdr(h, s->d_in, n, s->d_out, h.nbytes, typesize_override, s->d_work, q->work_bytes,
+                                     s->d_res, s->stream);
+    if (rc) { s->rc = rc; return ticket; }
+    if (hipMemcpyAsync(s->h_res, s->d_res, sizeof(hb_result), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return ticket;
+    s->state = SLOT_BUSY;
+    return ticket;
+}
+
+int64_t hb_queue_wait(hb_queue *q, int64_t ticket) {
+    if (!q || ticket < 0 || ticket >= q->next_ticket) return HB_ERR_BAD_ARG;
+    Slot &s = q->slots[(size_t)(ticket % (int64_t)q->slots.size())];
+    if (s.ticket != ticket || s.state == SLOT_FREE) return HB_ERR_BAD_ARG;    // already waited for, or overwritten
+    finish(q, s);
+    s.state = SLOT_FREE;
+    return s.rc;
+}
+
+}  // extern "C"

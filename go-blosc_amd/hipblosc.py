@@ -88,6 +88,7 @@ EXPORTS = [
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
+    "hb_queue_create", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
 
 
@@ -138,6 +139,10 @@ def lib():
             "hb_last_result_flags": (u32, []),
             "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
             "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),
+            "hb_queue_create": (vp, [i32, i32, sz]), "hb_queue_destroy": (None, [vp]),
+            "hb_queue_compress": (i64, [vp, vp, sz, vp, sz, i32, i32, i32, i32, u32]),
+            "hb_queue_decompress": (i64, [vp, vp, sz, vp, sz, i32]),
+            "hb_queue_wait": (i64, [vp, i64]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -351,3 +356,53 @@ def GetCodec(id):                          # codec.go:41-44
 
 def ListCodecs():                          # codec.go:47-53
     return list(codecs.keys())
+
+
+# ---------------------------------------------------------------------------------------------
+# pipelined host API (hb_queue_*): frames in flight, uploads / kernels / downloads overlapped
+# ---------------------------------------------------------------------------------------------
+class PinnedBuffer:
+    """hb_host_alloc() memory as a writable buffer (numpy: np.frombuffer(buf.view, np.uint8))."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().hb_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise HipBloscError("hb_host_alloc failed (no HIP device?)")
+        self.view = (ctypes.c_char * self.nbytes).from_address(self.ptr)
+
+    def close(self):
+        if self.ptr:
+            self.view = None
+            lib().hb_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+class FrameQueue:
+    """`depth` frames in flight on one device.  compress()/decompress() take raw addresses (PinnedBuffer.ptr or any host
+    address) and return a ticket; wait(ticket) returns the byte count or raises the reference's sentinel error."""
+
+    def __init__(self, max_nbytes, depth=3, dev=None):
+        self.q = lib().hb_queue_create(device if dev is None else dev, depth, max_nbytes)
+        if not self.q:
+            raise HipBloscError("hb_queue_create failed")
+
+    def compress(self, src_ptr, n, dst_ptr, cap, codec=LZ4, level=5, shuffle=Shuffle1, typesize=4, opts=0):
+        return _check(lib().hb_queue_compress(self.q, src_ptr, n, dst_ptr, cap, codec, level, shuffle, typesize, opts))
+
+    def decompress(self, frame_ptr, n, dst_ptr, cap, typesize=0):
+        return _check(lib().hb_queue_decompress(self.q, frame_ptr, n, dst_ptr, cap, typesize))
+
+    def wait(self, ticket):
+        return _check(lib().hb_queue_wait(self.q, ticket))
+
+    def close(self):
+        if self.q:
+            lib().hb_queue_destroy(self.q)
+            self.q = None
+
+    def __del__(self):
+        self.close()

@@ -160,6 +160,26 @@ int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *
                              void *const *dst, const size_t *cap, int64_t *rc,
                              int codec, int level, int shuffle, int typesize, unsigned opts);
 
+/* ---- pipelined host API: frames in flight on their own streams ----
+ * The one-call entry points above move H2D -> kernels -> D2H back to back, so a caller sees n / (t_h2d + t_k + t_d2h).
+ * A queue keeps `depth` frames in flight, each on its own stream with its own device buffers: the upload of frame k+1
+ * runs while frame k computes and frame k-1 downloads (PCIe is full duplex), so a stream of frames moves at the
+ * speed of the slower PCIe direction.  Same frame semantics as hb_compress_frame / hb_decompress_frame
+ * (blosc.go:320-434); LZ4 only.  src / dst must stay valid and untouched until hb_queue_wait() on the ticket
+ * returns; use hb_host_alloc() buffers (pageable memory works, but its copies do not overlap).
+ * A queue belongs to one thread at a time; different queues are independent. */
+typedef struct hb_queue hb_queue;
+hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes);   /* NULL on failure; frames up to max_nbytes uncompressed bytes */
+void hb_queue_destroy(hb_queue *q);                                     /* finishes what is in flight */
+/* enqueue one frame; returns a ticket >= 0 (tickets count up from 0) or an HB_ERR_* code.  When all `depth` slots are
+ * in flight the oldest one is finished first (its result is kept for its hb_queue_wait). */
+int64_t hb_queue_compress(hb_queue *q, const void *src, size_t n, void *dst, size_t cap,
+                          int codec, int level, int shuffle, int typesize, unsigned opts);
+int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst, size_t cap, int typesize_override);
+/* blocks until the frame is in dst; returns what hb_compress_frame / hb_decompress_frame would have returned.
+ * Tickets may be waited for in any order, each once, and not later than `depth` submissions after their own. */
+int64_t hb_queue_wait(hb_queue *q, int64_t ticket);
+
 #ifdef __cplusplus
 }
 #endif

@@ -380,3 +380,58 @@ def test_config5_device_shuffle_host_zstd(hb, O):
         g = bytearray(hb.Compress(O.synth(O.D_F32, 20000).tobytes(), hb.ZSTD, 3, hb.Shuffle1, 4))
         g[30] ^= 0xFF; g[40] ^= 0xFF
         hb.Decompress(bytes(g))
+
+
+def test_frame_queue_matches_one_call_api(hb, O):
+    # hb_queue_* (SURVEY.md §8 f1): frames in flight on their own streams must give exactly what the one-call API
+    # gives (same frames byte for byte, same decoded bytes), for mixed shapes, in and out of order, with slot reuse.
+    import ctypes
+    sizes = [4096 * 4 * 5, 100000, 1 << 20, 12, 333333, 4096 * 4 * 64, 7, 65536 * 4]
+    xs = [O.synth(O.D_F32, (s + 3) // 4, frame=k).tobytes()[:s] for k, s in enumerate(sizes)]
+    mx = max(sizes)
+    cap = hb.lib().hb_frame_bound(mx)
+    q = hb.FrameQueue(mx, depth=3)
+    pin_in = [hb.PinnedBuffer(mx) for _ in sizes]
+    pin_out = [hb.PinnedBuffer(cap) for _ in sizes]
+    modes = [(hb.Shuffle1, 4), (hb.BitShuffle, 4), (hb.NoShuffle, 1), (hb.Shuffle1, 8)]
+    tickets = []
+    for k, x in enumerate(xs):
+        ctypes.memmove(pin_in[k].ptr, x, len(x))
+        sh, ts = modes[k % 4]
+        tickets.append(q.compress(pin_in[k].ptr, len(x), pin_out[k].ptr, cap, hb.LZ4, 5, sh, ts, hb.OPT_INDEX_TRAILER))
+        if k >= 2:                                  # keep 3 in flight; wait for the oldest
+            j = k - 2
+            nb = q.wait(tickets[j])
+            sh, ts = modes[j % 4]
+            assert bytes(pin_out[j].view[:nb]) == hb.Compress(xs[j], hb.LZ4, 5, sh, ts, opts=hb.OPT_INDEX_TRAILER)
+    frames = {}
+    for j in (len(xs) - 1, len(xs) - 2):            # out of order
+        nb = q.wait(tickets[j])
+        sh, ts = modes[j % 4]
+        assert bytes(pin_out[j].view[:nb]) == hb.Compress(xs[j], hb.LZ4, 5, sh, ts, opts=hb.OPT_INDEX_TRAILER)
+    with pytest.raises(hb.HipBloscError):
+        q.wait(tickets[0])                          # a ticket is waited for once
+    # decode through the queue: frames from pin_out[k] back into pin_in[k]
+    for k, x in enumerate(xs):
+        sh, ts = modes[k % 4]
+        frames[k] = hb.Compress(x, hb.LZ4, 5, sh, ts, opts=hb.OPT_INDEX_TRAILER)
+        ctypes.memmove(pin_out[k].ptr, frames[k], len(frames[k]))
+    tk = [q.decompress(pin_out[k].ptr, len(frames[k]), pin_in[k].ptr, mx) for k in range(3)]
+    for k in range(3, len(xs)):
+        assert q.wait(tk[k - 3]) == len(xs[k - 3]) and bytes(pin_in[k - 3].view[:len(xs[k - 3])]) == xs[k - 3]
+        tk.append(q.decompress(pin_out[k].ptr, len(frames[k]), pin_in[k].ptr, mx))
+    for k in range(len(xs) - 3, len(xs)):
+        assert q.wait(tk[k]) == len(xs[k]) and bytes(pin_in[k].view[:len(xs[k])]) == xs[k]
+    # errors keep the reference's identities
+    with pytest.raises(hb.ErrInvalidData):
+        q.compress(pin_in[0].ptr, 0, pin_out[0].ptr, cap)                       # blosc.go:269-271
+    with pytest.raises(hb.ErrInvalidHeader):
+        q.decompress(pin_out[0].ptr, 8, pin_in[0].ptr, mx)                      # blosc.go:297-299
+    bad = bytearray(frames[1]); bad[20:40] = bytes(20)                          # corrupt payload + stale index
+    ctypes.memmove(pin_out[1].ptr, bytes(bad), len(bad))
+    t = q.decompress(pin_out[1].ptr, len(bad), pin_in[1].ptr, mx)
+    try:
+        q.wait(t)                                   # may decode to other bytes; must not fault (fuzz_test.go:135-159)
+    except (hb.ErrDecompressionFailed, hb.ErrSizeMismatch, hb.ErrInvalidData):
+        pass
+    q.close()
