@@ -153,6 +153,23 @@ __device__ __forceinline__ void dec_match_copy(uint8_t *s_out, uint32_t md, uint
             if (i < ml) v = s_out[md + i - off];
             if (i < ml) s_out[md + i] = v;
         }
+    } else if (off <= 4u && off != 3u && ml >= 128u) {
+        // a long run with period 1, 2 or 4 (what a shuffled plane of slowly varying values is made of): the period
+        // divides 4, so every aligned dword of the destination holds the same rotated pattern -- 16 bytes per lane
+        uint8_t *d = s_out + md;
+        const uint32_t *hw = (const uint32_t *)((uintptr_t)(d - 4) & ~(uintptr_t)3);
+        uint32_t w = __builtin_amdgcn_alignbyte(hw[1], hw[0], (uint32_t)((uintptr_t)(d - 4) & 3u));   // the 4 bytes before md
+        if (off == 1u) w = (w >> 24) * 0x01010101u;
+        else if (off == 2u) w = (w >> 16) * 0x00010001u;
+        // w = bytes for positions j = 0..3 (mod 4) relative to md; destination dwords start at j = head (mod 4)
+        const uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);
+        const uint32_t wr = __builtin_amdgcn_alignbyte(w, w, head & 3u);
+        if ((uint32_t)lane < head) d[lane] = (uint8_t)(w >> (8u * ((uint32_t)lane & 3u)));
+        const uint32_t nblk = (ml - head) >> 4;
+        u32x4 pat; pat.x = wr; pat.y = wr; pat.z = wr; pat.w = wr;
+        for (uint32_t b = lane; b < nblk; b += 64) *(u32x4 *)(d + head + 16u * b) = pat;
+        const uint32_t done = head + 16u * nblk;
+        if (done + (uint32_t)lane < ml) d[done + lane] = (uint8_t)(wr >> (8u * ((uint32_t)lane & 3u)));
     } else {                                                   // overlapping: the source is [md-off, md), repeated
         uint32_t m = (uint32_t)lane % off;
         const uint32_t step = 64u % off;
