@@ -73,6 +73,7 @@ int select_device(int device) {
     return HB_OK;
 }
 
+bool g_no_dec_fusion = false;              // hb_debug_decode_fusion(0): A/B switch for bench / tests
 thread_local unsigned g_last_flags = 0;   // hb_result.flags of the last host-pointer call on this thread
 
 bool overlap(const void *a, size_t na, const void *b, size_t nb) {
@@ -139,6 +140,7 @@ void hb_shutdown(void) {
 
 const char *hb_version(void) { return HB_VERSION_STRING; }
 unsigned hb_last_result_flags(void) { return g_last_flags; }
+void hb_debug_decode_fusion(int on) { g_no_dec_fusion = !on; }
 
 const char *hb_strerror(int code) {
     switch (code) {
@@ -378,7 +380,10 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     // whole windows (the serial fallback still goes through `staged` + a gated un-filter pass, hb_lz4_dec.hip)
     const bool fused_bun = unf == HB_OP_BITUNSHUFFLE && ts == 4 && (h.nbytes % 32u) == 0 && !(h.flags & HB_FLAG_MEMCPY) &&
                            ((uintptr_t)d_dst & 15u) == 0;
-    uint8_t *target = (unf >= 0 && !fused_bun) ? staged : (uint8_t *)d_dst;
+    // byte un-shuffle: fused into the indexed decoder (byte-strided stores) when the frame is whole planes of whole chunks
+    const bool fused_ush = unf == HB_OP_UNSHUFFLE && ts <= 16 && (h.nbytes % (uint32_t)ts) == 0 &&
+                           ((h.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && !(h.flags & HB_FLAG_MEMCPY) && !g_no_dec_fusion;
+    uint8_t *target = (unf >= 0 && !fused_bun && !fused_ush) ? staged : (uint8_t *)d_dst;
     const uint8_t *payload = (const uint8_t *)d_frame + HB_HEADER_SIZE;
     const size_t plen = h.cbytes - HB_HEADER_SIZE;
     hb_dec_args a{};
@@ -386,8 +391,9 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     a.work = dec_work; a.result = d_result; a.frame = 1; a.expect = h.nbytes;
     a.memcpy_payload = (h.flags & HB_FLAG_MEMCPY) ? 1 : 0;            // blosc.go:398-400
     a.fused_bitunshuffle4 = fused_bun ? 1 : 0;
+    a.fused_unshuffle_ts = fused_ush ? ts : 0;
     a.staged = staged;
-    if (fused_bun) unf = -1;                                          // nothing left to do after the decoder
+    if (fused_bun || fused_ush) unf = -1;                             // nothing left to do after the decoder
     // restart index, if any, sits after cbytes (ignored by the reference decoder, blosc.go:385-393)
     const size_t ioff = ((size_t)h.cbytes + 7) & ~(size_t)7;
     if (!a.memcpy_payload && n > ioff + 32) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }

@@ -41,7 +41,8 @@ struct hb_dec_args {
     int frame; uint32_t expect;          // frame != 0: decoded length must equal expect (blosc.go:429-431)
     int memcpy_payload;                  // blosc.go:398-400
     int fused_bitunshuffle4;             // the frame is bitshuffled with typesize 4 and the un-filter runs inside the decoder
-    uint8_t *staged;                     // fused_bitunshuffle4: where the serial fallback puts the still-filtered bytes
+    int fused_unshuffle_ts;              // != 0: the frame is byte-shuffled with this typesize and the un-shuffle runs inside the decoder
+    uint8_t *staged;                     // fused un-filter: where the serial fallback puts the still-filtered bytes
 };
 
 // hb_zstd.hip: host ZSTD behind the device filter (BASELINE.json config 5)

@@ -317,7 +317,11 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, con
 }
 __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
-                                                    DecPlan *plan, int bun4) {
+                                                    DecPlan *plan, int bun4, int ush) {
+    // ush != 0: the frame was byte-shuffled with typesize `ush` and has only whole planes of whole chunks; the un-shuffle is
+    // fused: a unit is a piece of ONE byte plane j, and its byte i goes straight to dst[(e0 + i) * ush + j] with byte
+    // stores (64 lanes cover 64 * ush bytes; the other planes' waves fill in the rest of those lines, and the
+    // memory-side cache merges the partial lines before they reach HBM) -- no filtered buffer, no un-shuffle pass.
     // bun4 != 0: the frame was bitshuffled with typesize 4 -- an in-place transform of every 32-byte window -- and the
     // un-filter is fused: every unit un-shuffles its own windows before they leave the chip (dst is the final output).
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_MAX + 128];
@@ -351,6 +355,10 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         if (last) ok = ok && s1 == n_src && d1 == nbytes;
         if (rem != HB_IDX_AT_TOKEN && tokpos >= n_src) ok = false;
         if (bun4 && ((d0 | d1) & 31u)) ok = false;              // fused un-filter works on whole 32-byte windows
+        const uint32_t ne = ush ? nbytes / (uint32_t)ush : 1u;  // bytes per plane
+        const uint32_t pj = ush ? d0 / ne : 0u;                 // my plane
+        if (ush && (pj >= (uint32_t)ush || d1 > (pj + 1u) * ne)) ok = false;   // a unit never straddles two planes
+        uint8_t *const udst = ush ? dst + (size_t)(d0 - pj * ne) * (uint32_t)ush + pj : dst + d0;
         if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
         const uint32_t slen = s1 - s0, outlen = d1 - d0;
         const uint8_t *g = src + s0;
@@ -361,7 +369,8 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             bool fine = slen == outlen;
             if (last) fine = fine && left == 0; else fine = fine && rem1 == left && tok1 == tokpos;
             if (!fine) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
-            if (!bun4) wave_copy_g2g(dst + d0, g, outlen, lane);
+            if (ush) { for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = g[i]; }
+            else if (!bun4) wave_copy_g2g(dst + d0, g, outlen, lane);
             else {
                 for (uint32_t w = lane; w < outlen / 32u; w += 64) {
                     u32x4 oa, ob;
@@ -456,7 +465,9 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             wave_sync();
         }
         // flush the chunk image
-        {
+        if (ush) {
+            for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
+        } else {
             uint8_t *o = dst + d0;
             uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);
             if (head > outlen) head = outlen;
@@ -685,18 +696,21 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
         const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u + 1u ? units : 256u * 64u + 1u));   // odd when capped
         hb_prof_begin("k_dec_indexed", s);
         hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan,
-                           a.fused_bitunshuffle4);
+                           a.fused_bitunshuffle4, a.fused_unshuffle_ts);
         hb_prof_end(s);
     }
     // with a fused un-filter the indexed decoder wrote FINAL bytes to a.dst; the serial decoder (if it has to run)
     // produces filtered bytes, so it goes to the staging buffer and the gated un-filter pass finishes the job
-    uint8_t *serial_dst = a.fused_bitunshuffle4 ? a.staged : a.dst;
+    const int fused_any = a.fused_bitunshuffle4 || a.fused_unshuffle_ts;
+    uint8_t *serial_dst = fused_any ? a.staged : a.dst;
     hb_prof_begin("k_dec_serial", s);
     hipLaunchKernelGGL(k_dec_serial, dim3(1), dim3(64), 0, s, a.src, (uint64_t)a.n, serial_dst, (uint64_t)a.cap, plan,
-                       a.result, a.frame, a.expect, a.fused_bitunshuffle4);
+                       a.result, a.frame, a.expect, fused_any);
     hb_prof_end(s);
-    if (a.fused_bitunshuffle4) {
-        const int rc = hb_launch_filter_gated(HB_OP_BITUNSHUFFLE, a.dst, a.staged, a.expect, 4, &plan->post, s);
+    if (fused_any) {
+        const int rc = a.fused_bitunshuffle4
+                           ? hb_launch_filter_gated(HB_OP_BITUNSHUFFLE, a.dst, a.staged, a.expect, 4, &plan->post, s)
+                           : hb_launch_filter_gated(HB_OP_UNSHUFFLE, a.dst, a.staged, a.expect, a.fused_unshuffle_ts, &plan->post, s);
         if (rc) return rc;
     }
     HB_HIP_TRY(hipGetLastError());

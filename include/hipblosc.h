@@ -91,6 +91,8 @@ const char *hb_strerror(int code);
 const char *hb_version(void);
 unsigned    hb_last_result_flags(void);    /* hb_result.flags of the last host-pointer frame decode on this thread
                                               (bit0: the restart index was used) — diagnostics for tests */
+void        hb_debug_decode_fusion(int on); /* A/B switch for bench / tests (default on): 0 = decode byte-shuffled frames with a
+                                              separate un-shuffle pass instead of the decoder's fused byte-strided stores */
 
 /* stage timing for the bench harness (single-threaded use): with enable(1) every kernel stage launched by the
  * `_dev` entry points is bracketed by HIP events on its stream; get(i) returns the stage name and its ms. */
