@@ -345,7 +345,21 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         P++;
     }
     for (uint32_t it = blockIdx.x; it < nunits; it += gridDim.x) {
-        const uint32_t u = (uint32_t)(((uint64_t)it * P) % nunits);
+        uint32_t u = (uint32_t)(((uint64_t)it * P) % nunits);
+        if (ush && nunits % (uint32_t)ush == 0u) {
+            // fused un-shuffle: the `ush` units that make up one 4096-element block write interleaved bytes of the same
+            // lines, so they get workgroup ids that are equal mod 8 (same XCD under round-robin placement: the
+            // partial lines meet in one L2) and run close in time; the plane rotates with the pass (planes differ in
+            // cost).  Within a group of 8 blocks, work item (plane j, block b % 8) has index j * 8 + b % 8.
+            const uint32_t T = (uint32_t)ush, nblk = nunits / T;
+            const uint32_t grp = it / (8u * T), r = it % (8u * T);
+            uint32_t b = grp * 8u + (r & 7u), j = ((r >> 3) + it / gridDim.x) % T;
+            if (grp * 8u + 8u > nblk) {                         // ragged last group: plain (b, j) order
+                const uint32_t k = it - grp * 8u * T, nb = nblk - grp * 8u;
+                b = grp * 8u + k % nb; j = k / nb;
+            }
+            u = j * nblk + b;
+        }
         const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
         const uint32_t s0 = e0.x, d0 = e0.y, s1 = e1.x, d1 = e1.y, rem1 = e1.z, tok1 = e1.w;
         uint32_t rem = e0.z, tokpos = e0.w;
@@ -693,7 +707,8 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
     hb_prof_end(s);
     if (a.index) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
-        const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u + 1u ? units : 256u * 64u + 1u));   // odd when capped
+        unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 64u + 1u ? units : 256u * 64u + 1u));   // odd when capped
+        if (a.fused_unshuffle_ts && grid > 256u * 64u) grid = 256u * 64u;   // a multiple of 8 * typesize: see the unit order in the kernel
         hb_prof_begin("k_dec_indexed", s);
         hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan,
                            a.fused_bitunshuffle4, a.fused_unshuffle_ts);
