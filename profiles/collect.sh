@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box from the repo root:  bash profiles/collect.sh <tag>   (outputs under gpurun_out/prof_<tag>/)
+# Passes: kernel trace + stats; FETCH_SIZE; WRITE_SIZE; SQ instruction mix.  --pmc is never combined with trace flags.
+set -e
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu > $O/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY --output-format csv -d $O/sq -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/sq.log 2>&1
+cd $R
+python3 profiles/summarize.py traffic $O/fetch $O/write $O/traffic.json "bench.py default: 1024 MiB D-f32 frame, Shuffle1 ts=4 + LZ4, index trailer, 1 GPU (MI355X)"
+python3 profiles/summarize.py counters $O/sq $O/sq.csv
+cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+tail -1 $O/trace.log | cut -c1-300
