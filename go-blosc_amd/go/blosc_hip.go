@@ -233,3 +233,57 @@ func CompressFramesHIP(frames [][]byte, opts Options, withIndex bool) ([][]byte,
 	}
 	return out, errs
 }
+
+// ---------------------------------------------------------------------------------------------
+// Pipelined frames (hb_queue_*): `depth` frames in flight on one device, uploads / kernels / downloads
+// overlapped — for callers that stream many frames (chunked arrays, inputs >= 4 GiB cut into frames).
+// Buffers handed to Submit* must be pinned (PinnedBytes) and stay untouched until Wait returns.
+// ---------------------------------------------------------------------------------------------
+
+// PinnedBytes returns a []byte backed by hb_host_alloc memory (free with FreePinned).  It holds no Go pointers
+// and is not moved by the GC, so the library may keep its address across the Submit/Wait pair.
+func PinnedBytes(n int) []byte  { return unsafe.Slice((*byte)(C.hb_host_alloc(C.size_t(n))), n) }
+func FreePinned(b []byte)       { C.hb_host_free(unsafe.Pointer(&b[0])) }
+
+type FrameQueue struct{ q *C.hb_queue }
+
+func NewFrameQueue(device, depth int, maxFrameBytes int) (*FrameQueue, error) {
+	q := C.hb_queue_create(C.int(device), C.int(depth), C.size_t(maxFrameBytes))
+	if q == nil {
+		return nil, fmt.Errorf("%w: hb_queue_create", ErrCompressionFailed)
+	}
+	return &FrameQueue{q}, nil
+}
+func (fq *FrameQueue) Close() { C.hb_queue_destroy(fq.q) }
+
+// SubmitCompress enqueues CompressWithOptions(src, opts) into dst (cap >= hb_frame_bound(len(src))); returns a ticket.
+func (fq *FrameQueue) SubmitCompress(src, dst []byte, opts Options, withIndex bool) (int64, error) {
+	var o C.uint
+	if withIndex {
+		o |= C.HB_OPT_INDEX_TRAILER
+	}
+	t := C.hb_queue_compress(fq.q, ptr(src), C.size_t(len(src)), ptr(dst), C.size_t(len(dst)),
+		C.int(opts.Codec), C.int(opts.Level), C.int(opts.Shuffle), C.int(opts.TypeSize), o)
+	if t < 0 {
+		return 0, hbError(t)
+	}
+	return int64(t), nil
+}
+
+// SubmitDecompress enqueues DecompressWithSize(frame, typeSize) into dst (cap >= NBytesOrig).
+func (fq *FrameQueue) SubmitDecompress(frame, dst []byte, typeSize int) (int64, error) {
+	t := C.hb_queue_decompress(fq.q, ptr(frame), C.size_t(len(frame)), ptr(dst), C.size_t(len(dst)), C.int(typeSize))
+	if t < 0 {
+		return 0, hbError(t)
+	}
+	return int64(t), nil
+}
+
+// Wait blocks until the ticket's frame is in its dst and returns the byte count (or the reference's error).
+func (fq *FrameQueue) Wait(ticket int64) (int, error) {
+	n := C.hb_queue_wait(fq.q, C.int64_t(ticket))
+	if n < 0 {
+		return 0, hbError(n)
+	}
+	return int(n), nil
+}
