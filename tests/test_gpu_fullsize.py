@@ -56,3 +56,35 @@ def test_headline_float32_shuffle4_lz4_1gib(hb, O):
     x = O.synth(O.D_F32, GIB // 4)
     ratio = _frame_case(hb, O, x, hb.Shuffle1, 4, bytes([2, 1, 1, 4]) + struct.pack("<II", GIB, GIB))
     assert ratio < 0.56            # ~0.52
+
+
+def test_maximum_frame_size(hb, O):
+    # The header's sizes are uint32 (blosc.go:159-161): the largest frame the format can hold is just under 4 GiB.
+    # One frame of that size through the whole path: offsets beyond 2^31 and payload bounds beyond 2^32 in every kernel.
+    import ctypes
+    L = hb.lib()
+    n = 4278190000                                   # largest multiple of 16 with n + n/255 + 80 <= 2^32 - 1
+    assert L.hb_compress_frame(ctypes.c_void_p(1), n + 256, ctypes.c_void_p(1), 0, hb.LZ4, 5, 0, 1, 0, 0) == -6   # ErrDataTooLarge
+    x = O.synth(O.D_F32, n // 4)
+    cap = L.hb_frame_bound(n)
+    out = np.empty(cap, np.uint8)
+    c = L.hb_compress_frame(x.ctypes.data, n, out.ctypes.data, cap, hb.LZ4, 5, hb.Shuffle1, 4, hb.OPT_INDEX_TRAILER, 0)
+    assert c > 16
+    h = hb.ParseHeader(out[:16].tobytes())
+    assert (h.NBytesOrig, h.BlockSize) == (n, n) and 16 < h.NBytesComp < n and not h.IsMemcpy()
+    assert 0.45 < h.NBytesComp / n < 0.56
+    back = np.empty(n, np.uint8)
+    assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, n, 0, 0) == n
+    assert L.hb_last_result_flags() & 1
+    assert np.array_equal(back, x.view(np.uint8)), "device round trip differs at the maximum frame size"
+    back[:] = 0
+    got = O.decompress_frame(out[:h.NBytesComp])     # the restated reference decoder, no index
+    assert np.array_equal(got, x.view(np.uint8)), "reference decoder cannot reproduce the input"
+    del got
+    # incompressible input of the same size: memcpy frame (blosc.go:342-345), cbytes = 16 + n still fits uint32
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 256, n, dtype=np.uint8)
+    c = L.hb_compress_frame(x.ctypes.data, n, out.ctypes.data, cap, hb.LZ4, 5, hb.NoShuffle, 1, hb.OPT_INDEX_TRAILER, 0)
+    assert c == n + 16 and hb.ParseHeader(out[:16].tobytes()).IsMemcpy()
+    assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, n, 0, 0) == n
+    assert np.array_equal(back, x)
