@@ -309,21 +309,31 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             cand = hit ? cand : (uint32_t)p - 1u;
             unsigned long long mask = m_hit | m_rle;
             if (mask) {
-                // every lane extends its own match to at most 12 bytes, branch-free: v_ffbl_b32 gives -1 for 0, so the
-                // first differing bit of the 8 bytes is min(ffbl(xa), 32 + min(ffbl(xb), 32))
-                uint32_t fa, fb;
+                // every lane extends its own match to at most 20 bytes, branch-free (two more dwords on each side, read
+                // on this path only): v_ffbl_b32 gives -1 for 0, so the first differing bit of the 16 bytes is
+                // min(ffbl(xa), 32 + min(ffbl(xb), 32 + min(ffbl(xc), 32 + min(ffbl(xd), 32))))
+                const uint32_t p4 = wp[4], p5 = wp[5], c4 = wc[4], c5 = wc[5];
+                const uint32_t v12 = __builtin_amdgcn_alignbyte(p4, p3, ap & 3u), v16 = __builtin_amdgcn_alignbyte(p5, p4, ap & 3u);
+                const uint32_t cv12 = __builtin_amdgcn_alignbyte(c4, c3, ac & 3u), cv16 = __builtin_amdgcn_alignbyte(c5, c4, ac & 3u);
+                const uint32_t xc = hit ? (cv12 ^ v12) : (b4 ^ v12), xd = hit ? (cv16 ^ v16) : (b4 ^ v16);
+                uint32_t fa, fb, fc, fd;
                 asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(xa));
                 asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(xb));
-                const uint32_t fbit = min(fa, min(fb, 32u) + 32u);
+                asm("v_ffbl_b32 %0, %1" : "=v"(fc) : "v"(xc));
+                asm("v_ffbl_b32 %0, %1" : "=v"(fd) : "v"(xd));
+                const uint32_t fbit = min(fa, min(fb, min(fc, min(fd, 32u) + 32u) + 32u) + 32u);
                 uint32_t ml = 4u + (fbit >> 3);
                 const uint32_t maxl = (uint32_t)(mend_max - p);
-                unsigned long long lmask = mask & hb_ballot(fbit == 64u) & hb_ballot(ml < maxl);
+                unsigned long long lmask = mask & hb_ballot(fbit == 128u) & hb_ballot(ml < maxl);
                 ml = min(ml, maxl);
                 if (lmask & m_rle & ~m_hit) {
                     // a run: the offset-1 match is the rest of the run, and the wave already knows where runs end as far
                     // as this window goes -- only a run that leaves the window needs the cooperative extension
                     const uint32_t run = (uint32_t)__builtin_ctzll(~(m_eqprev >> lane));
-                    const bool inwin = !hit && fbit == 64u && (uint32_t)lane + run < 64u;
+                    // a run that reaches the end of the window stops there if the next byte differs (bitshuffled data has
+                    // runs that end on 32-byte window boundaries all the time)
+                    const bool endstop = data[pos + 64] != data[pos + 63];
+                    const bool inwin = !hit && fbit == 128u && ((uint32_t)lane + run < 64u || ((uint32_t)lane + run == 64u && endstop));
                     if (inwin) ml = min(run, maxl);
                     lmask &= ~(hb_ballot(inwin) & m_rle);
                 }
@@ -429,7 +439,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
                                               uint32_t nchunks, int bits4) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 96];
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 template <int TS>
 __global__ __launch_bounds__(64) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
                                                     uint8_t *__restrict__ records, uint32_t nblk) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 96];
+    __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
