@@ -57,13 +57,15 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
     plan->mode = DEC_INDEXED;
 }
 
-#define DEC_IN_MAX  (HB_CHUNK + 512u)    // bytes of a unit's stream slice that are staged in LDS
+#define DEC_IN_WIN  2560u                // bytes of a unit's stream slice that are staged in LDS at a time (the window moves)
+#define DEC_IN_MARGIN 320u               // a token closer than this to the end of the window is parsed after re-staging
+#define DTQ 88                           // token queue slots: < 64 queued before a window is parsed, a window adds <= 22
 #define DEC_OUT_MAX HB_CHUNK             // largest output a unit may have
 
 // Sum of an LZ4 length extension (bytes 255 ... 255 r) starting at slice offset si, read cooperatively 64 bytes
 // at a time; bytes beyond the staged window come straight from HBM (a literal run of many MiB has an
 // extension of tens of KiB).  Returns false when the extension runs off the slice or is absurdly long.
-__device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged, const uint8_t *g, uint32_t slen,
+__device__ __forceinline__ bool dec_read_ext(const uint8_t *in, int inoff, uint32_t wlo, uint32_t staged, const uint8_t *g, uint32_t slen,
                                              uint32_t &si, uint32_t &acc, int lane) {
     uint64_t sum = acc;
     for (uint32_t round = 0;; round++) {
@@ -95,7 +97,7 @@ __device__ __forceinline__ bool dec_read_ext(const uint8_t *in, uint32_t staged,
         }
         const uint32_t i = si + lane;
         uint32_t b = 0;                                   // out of range reads as a terminator
-        if (i < slen) b = (i < staged) ? in[i] : g[i];
+        if (i < slen) b = (i >= wlo && i < staged) ? in[(uint32_t)((int)i + inoff)] : g[i];
         const unsigned long long stop = hb_ballot(b != 255u);
         if (stop == 0) { sum += 255u * 64u; si += 64; if (sum > 0xFFFFFFF0ull) return false; continue; }
         const int f = __builtin_ctzll(stop);
@@ -157,10 +159,10 @@ __device__ __forceinline__ void dec_match_copy(uint8_t *s_out, uint32_t md, uint
         // a long run with period 1, 2 or 4 (what a shuffled plane of slowly varying values is made of): the period
         // divides 4, so every aligned dword of the destination holds the same rotated pattern -- 16 bytes per lane
         uint8_t *d = s_out + md;
-        const uint32_t *hw = (const uint32_t *)((uintptr_t)(d - 4) & ~(uintptr_t)3);
-        uint32_t w = __builtin_amdgcn_alignbyte(hw[1], hw[0], (uint32_t)((uintptr_t)(d - 4) & 3u));   // the 4 bytes before md
-        if (off == 1u) w = (w >> 24) * 0x01010101u;
-        else if (off == 2u) w = (w >> 16) * 0x00010001u;
+        uint32_t w;                                             // the period, repeated to 4 bytes (md >= off: no read before the image)
+        if (off == 1u) w = (uint32_t)d[-1] * 0x01010101u;
+        else if (off == 2u) w = ((uint32_t)d[-2] | ((uint32_t)d[-1] << 8)) * 0x00010001u;
+        else w = (uint32_t)d[-4] | ((uint32_t)d[-3] << 8) | ((uint32_t)d[-2] << 16) | ((uint32_t)d[-1] << 24);
         // w = bytes for positions j = 0..3 (mod 4) relative to md; destination dwords start at j = head (mod 4)
         const uint32_t head = (uint32_t)((16u - ((uintptr_t)d & 15u)) & 15u);
         const uint32_t wr = __builtin_amdgcn_alignbyte(w, w, head & 3u);
@@ -199,7 +201,7 @@ __device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh,
         if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
         const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
         if (offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
-        const uint32_t x = dec_read4(s_in, sh + (cplx ? 0u : offpos));
+        const uint32_t x = dec_read4(s_in, sh + (cplx ? p : offpos));
         const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
         uint32_t mlen = 4u + mn, nbm = 0;
         if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
@@ -244,14 +246,14 @@ __device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh,
 // DRAIN: one queued token per lane, while 64 are queued (or `stop` and any are).  out[0] is the first byte of the image,
 // `hist` bytes before it are valid match sources, `outlen` is the room.  A token that does not fit is not decoded:
 // `rewound` is set and si goes back to that token.  Returns false on a match that reaches before out[-hist] or has offset 0.
-__device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, const uint32_t outlen, const uint32_t hist,
+__device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, uint8_t *s_out, const uint32_t outlen, const uint32_t hist,
                                           uint32_t &di, uint32_t &si, uint32_t &nq, uint2 *s_tq, const bool stop,
                                           bool &rewound, const int lane) {
     bool ok = true;
     while (nq >= 64u || (stop && nq > 0u)) {
         const uint32_t cntb = nq < 64u ? nq : 64u;
         const uint2 e = s_tq[lane];
-        const uint32_t lsrc = e.x & 0x1FFFu, lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22;
+        const uint32_t lsrc = (uint32_t)((int)(e.x & 0x1FFFu) + inoff), lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22;
         const uint32_t offv = e.y & 0xFFFFu, tp = e.y >> 16;
         const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
         const uint32_t incl = dec_incl_scan(olen, lane);
@@ -309,13 +311,13 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, uint8_t *s_out, con
         }
         di += total;
         if (rewound) { nq = 0; break; }
-        const uint2 rest = s_tq[64 + lane];              // keep what is queued beyond the 64 just decoded
+        const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];   // keep what is queued beyond the 64 just decoded
         nq -= cntb;
         if ((uint32_t)lane < nq) s_tq[lane] = rest;
     }
     return ok;
 }
-__global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
                                                     DecPlan *plan, int bun4, int ush) {
     // ush != 0: the frame was byte-shuffled with typesize `ush` and has only whole planes of whole chunks; the un-shuffle is
@@ -324,9 +326,9 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
     // memory-side cache merges the partial lines before they reach HBM) -- no filtered buffer, no un-shuffle pass.
     // bun4 != 0: the frame was bitshuffled with typesize 4 -- an in-place transform of every 32-byte window -- and the
     // un-filter is fused: every unit un-shuffles its own windows before they leave the chip (dst is the final output).
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_MAX + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_WIN + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
-    __shared__ __attribute__((aligned(16))) uint2 s_tq[128];     // parsed tokens waiting for their lane
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];     // parsed tokens waiting for their lane
     if (plan->mode != DEC_INDEXED) return;
     const int lane = threadIdx.x;
     const uint32_t nunits = plan->nunits;
@@ -396,18 +398,28 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
             continue;
         }
 
-        // stage the head of the slice (all of it, normally)
+        // stage a window of the slice (all of it, for a dense unit); `at` = slice position the window has to start at.
+        // LDS byte k of s_in is global byte g - sh + a16 + k, a16 a multiple of 16: 16-byte aligned vector loads.
         const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
-        const uint32_t staged = slen < DEC_IN_MAX - 16u ? slen : DEC_IN_MAX - 16u;
-        {
-            const u32x4 *ga = (const u32x4 *)(g - sh);
-            const uint32_t nv = (sh + staged + 15u) >> 4;
+        uint32_t wlo = 0, staged = 0;                           // the window holds slice positions [wlo, staged)
+        int shw = 0;                                            // LDS index of slice position p = p + shw
+        auto stage = [&](const uint32_t at) __attribute__((always_inline)) {
+            wave_sync();
+            const uint32_t a16 = (sh + at) & ~15u;
+            const uint32_t avail = sh + slen - a16;
+            const uint32_t cnt = avail < DEC_IN_WIN ? avail : DEC_IN_WIN;
+            const u32x4 *ga = (const u32x4 *)(g - sh + a16);
+            const uint32_t nv = (cnt + 15u) >> 4;
             for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_in)[i] = ga[i];
-        }
+            wlo = a16 > sh ? a16 - sh : 0u;
+            staged = a16 + cnt - sh;
+            shw = (int)sh - (int)a16;
+            wave_sync();
+        };
+        stage(0u);
         uint32_t tok = 0;
         if (rem != HB_IDX_AT_TOKEN) tok = src[tokpos];
-        wave_sync();
-        const uint8_t *in = s_in + sh;
+#define INB(i) s_in[(uint32_t)((int)(i) + shw)]              /* stream byte at slice position i (inside the window) */
         uint32_t si = 0, di = 0;
         bool at_token = false;       // state when the unit stops
         bool done = false;
@@ -418,45 +430,48 @@ __global__ __launch_bounds__(64) void k_dec_indexed(const uint8_t *__restrict__ 
         int slow = 1;
         uint32_t nq = 0;                                        // tokens queued in s_tq
         if (rem == HB_IDX_AT_TOKEN) { rem = 0; slow = 0; }
-        const uint32_t lim = staged;                            // the window parser only looks at staged bytes
         while (ok && !done) {
             if (slow) {
                 if (slow == 2) {
                     if (si >= slen) { ok = false; break; }
                     tokpos = s0 + si;
-                    tok = (si < staged) ? in[si] : g[si];
+                    tok = (si >= wlo && si < staged) ? INB(si) : g[si];
                     si++;
                     rem = tok >> 4;
-                    if (rem == 15u && !dec_read_ext(in, staged, g, slen, si, rem, lane)) { ok = false; break; }
+                    if (rem == 15u && !dec_read_ext(s_in, shw, wlo, staged, g, slen, si, rem, lane)) { ok = false; break; }
                 }
                 slow = 0;
                 {   // literal phase
                     const uint32_t take = min(rem, outlen - di);
                     if (take > slen - si) { ok = false; break; }
-                    if (si + take <= staged) { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = in[si + i]; }
+                    if (si >= wlo && si + take <= staged) { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = INB(si + i); }
                     else { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = g[si + i]; }
                     si += take; di += take; rem -= take;
                 }
                 if (rem > 0 || di == outlen) { at_token = false; done = true; break; }
                 // match phase
                 if (slen - si < 2) { ok = false; break; }             // also: block ends after literals -> serial decides
-                const uint32_t b0 = (si < staged) ? in[si] : g[si], b1 = (si + 1 < staged) ? in[si + 1] : g[si + 1];
+                const uint32_t b0 = (si >= wlo && si < staged) ? INB(si) : g[si], b1 = (si + 1 >= wlo && si + 1 < staged) ? INB(si + 1) : g[si + 1];
                 const uint32_t offset = b0 | (b1 << 8);
                 si += 2;
                 uint32_t mlen = (tok & 15u) + 4u;
-                if ((tok & 15u) == 15u && !dec_read_ext(in, staged, g, slen, si, mlen, lane)) { ok = false; break; }
+                if ((tok & 15u) == 15u && !dec_read_ext(s_in, shw, wlo, staged, g, slen, si, mlen, lane)) { ok = false; break; }
                 if (offset == 0 || offset > di || mlen > outlen - di) { ok = false; break; }
                 dec_match_copy(s_out, di, offset, mlen, lane);
                 di += mlen;
                 continue;
             }
-            const bool stop = dec_fill(s_in, sh, lim, slen, si, nq, s_tq, lane);
+            if (nq == 0u && staged < slen && si + DEC_IN_MARGIN > staged) {     // move the window (queued tokens point into it)
+                stage(si);
+            }
+            const bool stop = dec_fill(s_in, (uint32_t)shw, staged, slen, si, nq, s_tq, lane);
             bool rewound = false;
-            ok = dec_drain(in, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
+            ok = dec_drain(s_in, shw, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
             if (!ok) break;
             if (rewound) { slow = 2; continue; }
             if (stop) {
                 if (si == slen || di == outlen) { at_token = true; done = true; }
+                else if (staged < slen && si + DEC_IN_MARGIN > staged) continue;   // stopped at the end of the window, not at a complex token
                 else slow = 2;
             }
         }
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
     // really decodes it raises plan->post so that the gated un-filter pass behind it runs
     __shared__ __attribute__((aligned(16))) uint8_t s_win[SER_WIN + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_img[SER_HIST + SER_PAGE + 1024];
-    __shared__ __attribute__((aligned(16))) uint2 s_tq[128];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     const int lane = threadIdx.x;
     if (plan->mode == DEC_INDEXED && !plan->fail) {
         if (lane == 0) {
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
             const uint32_t hist = (uint32_t)(gbase < (uint64_t)SER_HIST ? gbase : (uint64_t)SER_HIST);
             const bool stop = dec_fill(s_win, wsh, wlen, wlen, rel, nq, s_tq, lane);
             bool rewound = false;
-            if (!dec_drain(s_win + wsh, out, SER_PAGE, hist, di, rel, nq, s_tq, true, rewound, lane)) { err = 1; break; }
+            if (!dec_drain(s_win + wsh, 0, out, SER_PAGE, hist, di, rel, nq, s_tq, true, rewound, lane)) { err = 1; break; }
             const bool moved = (wpos + rel) != si;
             si = wpos + rel;
             if (rewound) continue;                                    // page full: flush, then go on from that token
@@ -613,7 +628,7 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
             uint32_t ll = tok >> 4;
             if (ll == 15u) {
                 const uint64_t span = n_src - wpos;
-                if (!dec_read_ext(s_win + wsh, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { err = 1; break; }
+                if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { err = 1; break; }
             }
             si = wpos + rel;
             lrem = ll;
@@ -656,7 +671,7 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
                 if (si < wpos || si - wpos + 64u > wlen) refill(si);
                 uint32_t rel = (uint32_t)(si - wpos);
                 const uint64_t span = n_src - wpos;
-                if (!dec_read_ext(s_win + wsh, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ml, lane)) { err = 1; break; }
+                if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ml, lane)) { err = 1; break; }
                 si = wpos + rel;
             }
             if ((uint64_t)moff > gbase + di) { err = 1; break; }      // before the start of the block (no dictionary)
