@@ -53,6 +53,34 @@ const ZstdApi *zstd_api() {
 
 constexpr size_t SLICE = 16u << 20;
 
+// grow-only caches of the staging buffers (pinning 1 GiB of host memory or hipMalloc-ing it costs tens of milliseconds;
+// a host-bound codec should not pay that per frame).  hb_shutdown() does not free these; they live with the process.
+struct Cached { void *p; size_t bytes; int dev; bool host; };
+std::mutex g_cache_mu;
+std::vector<Cached> g_cache;
+void *cache_get(bool host, int dev, size_t bytes, size_t *got) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (!bytes) bytes = 4096;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_cache.size(); i++)
+            if (g_cache[i].host == host && (host || g_cache[i].dev == dev) && g_cache[i].bytes >= bytes &&
+                (best < 0 || g_cache[i].bytes < g_cache[best].bytes)) best = i;
+        if (best >= 0) { Cached c = g_cache[best]; g_cache.erase(g_cache.begin() + best); *got = c.bytes; return c.p; }
+    }
+    void *p = nullptr;
+    const hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+    if (e != hipSuccess) return nullptr;
+    *got = bytes;
+    return p;
+}
+void cache_put(bool host, int dev, void *p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.push_back(Cached{p, bytes, dev, host});
+}
+
 int host_threads() {
     unsigned n = std::thread::hardware_concurrency();
     if (n == 0) n = 4;
@@ -85,14 +113,17 @@ int64_t hb_zstd_compress_frame(const void *src, size_t n, void *dst, size_t cap,
     // ---- filtered image: device filter, copied back slice by slice ----
     uint8_t *h_f = nullptr;            // pinned host copy of the filtered buffer
     uint8_t *d_src = nullptr, *d_f = nullptr;
+    size_t b_src = 0, b_f = 0, b_h = 0;
     hipStream_t st = nullptr;
     std::vector<hipEvent_t> ev(nsl, nullptr);
     const uint8_t *payload_src = (const uint8_t *)src;
     int rc = HB_OK;
     if (filt) {
         if (hipSetDevice(device) != hipSuccess) return HB_ERR_HIP;
-        if (hipMalloc((void **)&d_src, n) != hipSuccess || hipMalloc((void **)&d_f, n) != hipSuccess ||
-            hipHostMalloc((void **)&h_f, n, hipHostMallocDefault) != hipSuccess || hipStreamCreate(&st) != hipSuccess) rc = HB_ERR_HIP;
+        d_src = (uint8_t *)cache_get(false, device, n, &b_src);
+        d_f = (uint8_t *)cache_get(false, device, n, &b_f);
+        h_f = (uint8_t *)cache_get(true, device, n, &b_h);
+        if (!d_src || !d_f || !h_f || hipStreamCreate(&st) != hipSuccess) rc = HB_ERR_HIP;
         if (!rc && hipMemcpyAsync(d_src, src, n, hipMemcpyHostToDevice, st) != hipSuccess) rc = HB_ERR_HIP;
         if (!rc) rc = hb_launch_filter(shuffle == HB_SHUFFLE ? HB_OP_SHUFFLE : HB_OP_BITSHUFFLE, d_f, d_src, n, typesize, st);
         for (size_t i = 0; i < nsl && !rc; i++) {
@@ -151,10 +182,10 @@ int64_t hb_zstd_compress_frame(const void *src, size_t n, void *dst, size_t cap,
         ret = (int64_t)(HB_HEADER_SIZE + total);
     }
     for (auto e : ev) if (e) (void)hipEventDestroy(e);
-    if (st) (void)hipStreamDestroy(st);
-    if (d_src) (void)hipFree(d_src);
-    if (d_f) (void)hipFree(d_f);
-    if (h_f) (void)hipHostFree(h_f);
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }   // nothing in flight when the buffers go back
+    cache_put(false, device, d_src, b_src);
+    cache_put(false, device, d_f, b_f);
+    cache_put(true, device, h_f, b_h);
     return ret;
 }
 
@@ -171,11 +202,13 @@ int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *ds
     if ((h.flags & HB_FLAG_BITSHUFFLE) && ts > 1) unf = HB_OP_BITUNSHUFFLE;                // blosc.go:422-426
     else if ((h.flags & HB_FLAG_SHUFFLE) && ts > 1) unf = HB_OP_UNSHUFFLE;
     uint8_t *h_f = nullptr, *d_a = nullptr, *d_b = nullptr;
+    size_t b_h = 0, b_a = 0, b_b = 0;
     uint8_t *target = (uint8_t *)dst;
     int rc = HB_OK;
     if (unf >= 0) {
         if (hipSetDevice(device) != hipSuccess) return HB_ERR_HIP;
-        if (hipHostMalloc((void **)&h_f, n ? n : 1, hipHostMallocDefault) != hipSuccess) return HB_ERR_HIP;
+        h_f = (uint8_t *)cache_get(true, device, n, &b_h);
+        if (!h_f) return HB_ERR_HIP;
         target = h_f;
     }
     // frame table: every zstd frame with a known content size becomes one task
@@ -216,13 +249,15 @@ int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *ds
     }
     if (!rc && got != n) rc = HB_ERR_SIZE_MISMATCH;                   // blosc.go:429-431
     if (!rc && unf >= 0 && n) {
-        if (hipMalloc((void **)&d_a, n) != hipSuccess || hipMalloc((void **)&d_b, n) != hipSuccess) rc = HB_ERR_HIP;
+        d_a = (uint8_t *)cache_get(false, device, n, &b_a);
+        d_b = (uint8_t *)cache_get(false, device, n, &b_b);
+        if (!d_a || !d_b) rc = HB_ERR_HIP;
         if (!rc && hipMemcpy(d_a, h_f, n, hipMemcpyHostToDevice) != hipSuccess) rc = HB_ERR_HIP;
         if (!rc) rc = hb_launch_filter(unf, d_b, d_a, n, ts, nullptr);
         if (!rc && hipMemcpy(dst, d_b, n, hipMemcpyDeviceToHost) != hipSuccess) rc = HB_ERR_HIP;
     }
-    if (d_a) (void)hipFree(d_a);
-    if (d_b) (void)hipFree(d_b);
-    if (h_f) (void)hipHostFree(h_f);
+    cache_put(false, device, d_a, b_a);                               // the copies above were synchronous
+    cache_put(false, device, d_b, b_b);
+    cache_put(true, device, h_f, b_h);
     return rc ? (int64_t)rc : (int64_t)n;
 }
