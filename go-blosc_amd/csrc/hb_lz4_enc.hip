@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 // workgroup ids that are equal mod 8 (same XCD under round-robin placement: they share the L2 lines -- speed
 // only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
 template <int TS>
-__global__ __launch_bounds__(64) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
                                                     uint8_t *__restrict__ records, uint32_t nblk) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
