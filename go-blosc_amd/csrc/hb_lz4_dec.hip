@@ -31,7 +31,8 @@ struct DecPlan {
     uint32_t nunits;
     uint32_t nbytes;      // decoded size the index declares
     uint32_t post;        // set by k_dec_serial when it decoded into the staging buffer: the gated un-filter must run
-    uint32_t pad[3];
+    uint32_t stride;      // unit order of the indexed decoder: u = i * stride mod nunits, gcd(stride, nunits) == 1
+    uint32_t pad[2];
 };
 enum { DEC_SERIAL = 0, DEC_INDEXED = 1 };
 
@@ -42,7 +43,7 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return ld4u(p); }
 // 1 thread: is there a usable index?
 __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_bytes, uint64_t n_src, uint64_t cap,
                            DecPlan *plan, hb_result *result) {
-    plan->mode = DEC_SERIAL; plan->fail = 0; plan->nunits = 0; plan->nbytes = 0; plan->post = 0;
+    plan->mode = DEC_SERIAL; plan->fail = 0; plan->nunits = 0; plan->nbytes = 0; plan->post = 0; plan->stride = 1;
     result->status = HB_OK; result->flags = 0; result->bytes = 0; result->total_bytes = 0; result->reserved = 0;
     if (!index || index_bytes < HB_IDX_HDR_BYTES + 2 * HB_IDX_ENTRY) return;
     uint32_t h[8];
@@ -54,6 +55,14 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
     if (h[4] != n_src || h[5] > cap) return;
     plan->nunits = (uint32_t)nunits;
     plan->nbytes = h[5];
+    uint32_t P = (uint32_t)nunits / 4u + 1u;                 // about a quarter turn per step (next byte plane of a shuffled frame)
+    for (;;) {
+        uint32_t x = P, y = (uint32_t)nunits;
+        while (y) { const uint32_t t = x % y; x = y; y = t; }
+        if (x == 1u) break;
+        P++;
+    }
+    plan->stride = P;
     plan->mode = DEC_INDEXED;
 }
 
@@ -339,13 +348,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     // nunits/4): neighbouring workgroups then work on far-apart parts of the buffer (different byte planes of a
     // shuffled frame: issue-bound token-dense units next to bandwidth-bound literal-only ones), and the odd grid
     // size rotates the mix from pass to pass.  Any order is correct: units are independent.
-    uint32_t P = nunits / 4u + 1u;
-    for (;;) {                                              // gcd(P, nunits) == 1
-        uint32_t x = P, y = nunits;
-        while (y) { const uint32_t t = x % y; x = y; y = t; }
-        if (x == 1u) break;
-        P++;
-    }
+    const uint32_t P = plan->stride;                        // computed once by k_dec_plan
     for (uint32_t it = blockIdx.x; it < nunits; it += gridDim.x) {
         uint32_t u = (uint32_t)(((uint64_t)it * P) % nunits);
         if (ush && nunits % (uint32_t)ush == 0u) {
