@@ -37,7 +37,7 @@
 // bytes of the source read a second time by k_stitch; see DESIGN.md.
 #include "hb_lz4.h"
 
-#define HLOG 10
+#define HLOG 9
 #define HSIZE (1u << HLOG)
 #define LITCAP 16u          // literal runs up to this long are copied by the owning lane, longer ones by the wave
 
@@ -132,7 +132,7 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 }
 
 #define QCAP 80             // sequence queue slots: flushed once 64 are queued, and a step adds at most 16 (matches are >= 4 bytes)
-#define SOUT 1280u          // bytes of record staging per wave: drained to the record in HBM after every flush (LDS per wave
+#define SOUT 768u           // bytes of record staging per wave: drained to the record in HBM after every flush (LDS per wave
                             // sets the number of resident waves, and the matcher is latency-bound: time ~ 1 / waves)
 
 // One chunk, one wavefront.  The chunk image is in LDS (byte i of the chunk at s_data[sh + i]); s_out / s_tab /
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 // workgroup ids that are equal mod 8 (same XCD under round-robin placement: they share the L2 lines -- speed
 // only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
 template <int TS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
                                                     uint8_t *__restrict__ records, uint32_t nblk) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
