@@ -388,7 +388,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             bool fine = slen == outlen;
             if (last) fine = fine && left == 0; else fine = fine && rem1 == left && tok1 == tokpos;
             if (!fine) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
-            if (ush) { for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = g[i]; }
+            if (ush) {                                          // wide loads (any alignment) into the image, then the strided stores
+                for (uint32_t i = lane * 16u; i < outlen; i += 1024u) {
+                    if (i + 16u <= outlen) *(u32x4 *)(s_out + i) = ld16u(g + i);
+                    else for (uint32_t r = i; r < outlen; r++) s_out[r] = g[r];
+                }
+                wave_sync();
+                for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
+                wave_sync();
+            }
             else if (!bun4) wave_copy_g2g(dst + d0, g, outlen, lane);
             else {
                 for (uint32_t w = lane; w < outlen / 32u; w += 64) {
