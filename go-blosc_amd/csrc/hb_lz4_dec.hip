@@ -470,6 +470,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 if (offset == 0 || offset > di || mlen > outlen - di) { ok = false; break; }
                 dec_match_copy(s_out, di, offset, mlen, lane);
                 di += mlen;
+                // peek: a next token with a multi-byte match extension would come straight back from the window parser
+                // (highly compressible units are a handful of such tokens): stay on this path
+                if (si >= wlo && si + 4u <= staged && di < outlen) {
+                    const uint32_t t2 = INB(si), l2 = t2 >> 4;
+                    if (l2 < 15u && (t2 & 15u) == 15u) {
+                        const uint32_t op = si + 1u + l2;
+                        if (op + 3u <= staged && INB(op + 2u) == 255u) slow = 2;
+                    }
+                }
                 continue;
             }
             if (nq == 0u && staged < slen && si + DEC_IN_MARGIN > staged) {     // move the window (queued tokens point into it)
