@@ -140,18 +140,36 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 // un-matched tail of the chunk to the record (fused filter: there is no filtered buffer in HBM for k_stitch to
 // take literals from; a chunk without any match then stores its whole image).
 __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_t sh, const int len,
-                                            uint8_t *s_out /* SOUT + 16 */, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */,
+                                            uint8_t *s_out /* SOUT + 16 */, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */, uint32_t *s_st /* 8 words */,
                                             ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const int lane) {
     {
         {
             u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
             for (uint32_t i = lane; i < HSIZE * 2 / 16; i += 64) ((u32x4 *)s_tab)[i] = z;
+            if (lane < 2) ((u32x4 *)s_st)[lane] = z;
         }
         wave_sync();
 
-        int pos = 0, anchor = 0, nq = 0, nseq = 0, miss = 0;
+        int pos = 0, anchor = 0, nq = 0, miss = 0;
+        // Emission state.  It changes once per flush (every ~64 sequences), so between flushes it lives in LDS (s_st): as
+        // loop-carried scalars each of these costs the step loop two register copies per step.
+        int nseq = 0;                                     // sequences emitted so far
         uint32_t rec_done = 0, opend = 0;                 // record bytes already in HBM (multiple of 16) / pending in s_out
         uint32_t batch_anchor = 0, lead = 0, mcode0 = 0;
+        auto ld_state = [&]() __attribute__((always_inline)) {
+            const u32x4 a = ((const u32x4 *)s_st)[0], b = ((const u32x4 *)s_st)[1];
+            nseq = (int)__builtin_amdgcn_readfirstlane(a.x); batch_anchor = __builtin_amdgcn_readfirstlane(a.y);
+            lead = __builtin_amdgcn_readfirstlane(a.z); mcode0 = __builtin_amdgcn_readfirstlane(a.w);
+            rec_done = __builtin_amdgcn_readfirstlane(b.x); opend = __builtin_amdgcn_readfirstlane(b.y);
+        };
+        auto st_state = [&]() __attribute__((always_inline)) {
+            if (lane == 0) {
+                u32x4 a, b;
+                a.x = (uint32_t)nseq; a.y = batch_anchor; a.z = lead; a.w = mcode0; b.x = rec_done; b.y = opend; b.z = 0; b.w = 0;
+                ((u32x4 *)s_st)[0] = a; ((u32x4 *)s_st)[1] = b;
+            }
+            wave_sync();
+        };
         const int mstart_max = len - 12;                  // last position a match may start at
         const int mend_max = len - 5;                     // matches end at or before this
         const uint8_t *data = s_data + sh;
@@ -184,6 +202,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 
         // emit queued sequences, one per lane: as many of the first min(nq, 64) as fit into s_out
         auto flush = [&]() __attribute__((always_inline)) {
+            ld_state();
             const int take = nq < 64 ? nq : 64;
             const uint2 e = s_q[lane];
             const uint32_t q_mp = e.x & 0xFFFFu, q_ml = e.x >> 16, q_off = e.y;
@@ -269,6 +288,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             nq -= cnt;
             if (lane < nq) s_q[lane] = r0;
             if (lane + 64 < nq) s_q[lane + 64] = r1;
+            st_state();
         };
 
         while (pos <= mstart_max) {
@@ -412,6 +432,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             pos = anchor > nxt ? anchor : nxt;
         }
         while (nq > 0) flush();
+        ld_state();
         const uint32_t enc = rec_done + opend;             // record bytes without the trailing literals
         if (with_trailing) {
             if (nseq == 0 && sh == 0) {            // no match at all: the record is the image itself
@@ -443,6 +464,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_st[8];
     const int lane = threadIdx.x;
     for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
         const uint64_t start = (uint64_t)ck * HB_CHUNK;
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 ((u32x4 *)s_data)[2 * w + 1] = ob;
             }
         }
-        match_chunk(s_data, sh, len, s_out, s_tab, s_q, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, lane);
+        match_chunk(s_data, sh, len, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, lane);
     }
 }
 
@@ -479,6 +501,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_st[8];
     const int lane = threadIdx.x;
     const uint32_t total = nblk * TS;
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
@@ -536,7 +559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             }
         }
         const uint32_t ck = j * nblk + b;
-        match_chunk(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, lane);
+        match_chunk(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, lane);
     }
 }
 
