@@ -464,7 +464,9 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_st[8];
+    // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
+    // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
+    uint32_t *const s_st = (uint32_t *)(s_data + HB_CHUNK + 80);
     const int lane = threadIdx.x;
     for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
         const uint64_t start = (uint64_t)ck * HB_CHUNK;
@@ -501,7 +503,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_st[8];
+    // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
+    // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
+    uint32_t *const s_st = (uint32_t *)(s_data + HB_CHUNK + 80);
     const int lane = threadIdx.x;
     const uint32_t total = nblk * TS;
     for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
