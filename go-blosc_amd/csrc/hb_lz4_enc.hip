@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint32_t sel = 0x0c0c0000u | ((4u + rb) << 8) | rb;      // {lo.byte rb, hi.byte rb, 0, 0}
             constexpr int NV = TS / 4;                                      // 16-byte vectors per 4 elements
             constexpr int STEPS = (int)(HB_CHUNK / 256);
-            constexpr int BATCH = (16 / NV) < STEPS ? (16 / NV) : STEPS;   // steps per batch (<= 16 vectors in flight)
+            constexpr int BATCH = (8 / NV) < STEPS ? (8 / NV) : STEPS;     // steps per batch (<= 8 vectors in flight: 32 VGPRs, the kernel is capped at 80)
             static_assert(STEPS % BATCH == 0, "chunk size must be a multiple of the staging batch");
 #pragma unroll 1
             for (int it0 = 0; it0 < (int)(HB_CHUNK / 256); it0 += BATCH) {  // 4 elements (4*TS bytes) per lane per step
