@@ -5,13 +5,15 @@
 //
 //   k_dec_indexed : for blocks that come with a restart index (HBIX, see hb_lz4.h) — every block this
 //       library encodes.  One wavefront per index unit (= one 4 KiB chunk of output), the unit's slice of the
-//       stream staged in LDS.  FILL: the 64 lanes parse 64 stream bytes "as if a token started at my byte"; the
+//       stream staged in LDS through a moving 2.5 KiB window (7.4 KiB of LDS per wave, 20 waves per CU).  FILL: the 64 lanes parse 64 stream bytes "as if a token started at my byte"; the
 //       real token chain is followed with one s_bitset1_b64 + one v_readlane per token and the real tokens are
 //       compacted into an LDS queue.  DRAIN: one queued token per lane — a wave scan gives the output positions,
 //       every lane copies its own literals and its own match into an LDS image of the chunk (dependency rounds: a
 //       match is ready when its source ends before the first pending match or lies in the lane's own literals;
 //       overlapping matches by pattern replication), long ones are copied by the whole wave; the image is flushed
-//       with coalesced 16-byte stores.  Literal-only units go HBM -> HBM.  Tokens with multi-byte length
+//       with coalesced 16-byte stores -- or, for byte-shuffled frames with typesize 2 / 4, straight to the
+//       un-shuffled positions with byte-strided stores (filter fused; bitshuffle with typesize 4 likewise, as an
+//       in-place transform of the image).  Literal-only units go HBM -> HBM.  Tokens with multi-byte length
 //       extensions, or at the edges of the unit, take a one-sequence-at-a-time slow path.  The index is NOT
 //       trusted: each unit checks that it ends exactly in the state the next entry claims (stream offset, output
 //       offset, literals left in the current run, token position) and that no match reaches before its

@@ -8,19 +8,22 @@
 //              the image straight from the un-filtered source: byte shuffle fused, no filtered buffer in HBM).
 //              Every step the 64 lanes look at 64 consecutive positions: 12 bytes at the position and 12 at the
 //              table candidate (aligned dwords + v_alignbyte: a misaligned ds_read_b32 is replayed), hash of the first
-//              4, probe / insert into a 1024-entry u16 table in LDS, verify, and a branch-free extension to at most
-//              12 bytes.  Positions inside a run of equal 4-grams are not inserted, so the table keeps run STARTS
-//              (a candidate at the end of a run cannot be extended), and such positions fall back to the offset-1
-//              candidate, whose length comes from the same 12 bytes.  Greedy left-to-right selection: every hit
-//              lane computes its successor (first hit at or after the end of its match), then the chain is walked
-//              with one s_bitset1_b64 + one v_readlane per sequence; matches still going after 12 bytes are extended
-//              cooperatively, 256 bytes per step.  Selected matches are compacted (v_mbcnt) into an LDS queue and
-//              emitted 64 at a time, lane-parallel: sizes -> wave prefix sum -> every lane writes its own token /
-//              extension / literals / offset into an LDS image of the record, which is flushed with coalesced
-//              16-byte stores.  After 4 steps without a hit the scan strides over 64-byte gaps (LZ4's skip
-//              acceleration).  Matches never leave the chunk; the last 5 bytes of a chunk stay literals and no
-//              match starts in its last 12 (LZ4 end-of-block rules, applied per chunk so the very last chunk
-//              satisfies them).
+//              4, probe / insert into a 512-entry u16 table in LDS, verify, and -- when any lane hit -- a branch-free
+//              extension to at most 20 bytes.  Positions inside a run of equal 4-grams are not inserted, so the table
+//              keeps run STARTS (a candidate at the end of a run cannot be extended), and such positions fall back to
+//              the offset-1 candidate, whose length comes from the wave-wide "equals the byte before" mask as far
+//              as the 64-position window goes.  Greedy left-to-right selection: every hit lane computes its successor
+//              (first hit at or after the end of its match; the last one points at itself), then the chain is walked
+//              with one s_bitset1_b64 + one v_readlane per sequence, unrolled by 4; matches still going after 20 bytes
+//              (or runs that leave the window) are extended cooperatively, 256 bytes per step.  Selected matches are
+//              compacted (v_mbcnt) into an LDS queue and emitted up to 64 at a time, lane-parallel: sizes -> DPP
+//              prefix sum -> every lane writes its own token / extension / literals / offset into a 768-byte staging
+//              buffer, which is drained to the record with 16-byte stores after every flush (a 4 KiB record image
+//              would cost the occupancy the kernel lives on: time x resident waves is constant up to ~16 waves per
+//              CU; 6.5 KiB of LDS and 80 VGPRs give 24).  The emission state lives in LDS between flushes.  After 4
+//              steps without a hit the scan strides over 64-byte gaps (LZ4's skip acceleration).  Matches never
+//              leave the chunk; the last 5 bytes of a chunk stay literals and no match starts in its last 12 (LZ4
+//              end-of-block rules, applied per chunk so the very last chunk satisfies them).
 //              Record:  [lead literals][rest of sequence 0][sequence 1]...[sequence m-1]  (+ [trailing literals] when fused)
 //              Sequence 0 has no token yet: its literal run also contains whatever the previous chunks
 //              left un-matched, which only the scan knows.
