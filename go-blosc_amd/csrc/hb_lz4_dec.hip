@@ -368,8 +368,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
             u = j * nblk + b;
         }
         const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
-        const uint32_t s0 = e0.x, d0 = e0.y, s1 = e1.x, d1 = e1.y, rem1 = e1.z, tok1 = e1.w;
-        uint32_t rem = e0.z, tokpos = e0.w;
+        // wave-uniform values that come out of vector loads are moved to scalar registers: the compiler cannot know
+        // they are uniform, and would otherwise run the whole state machine on the vector side under exec masks
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+        const uint32_t s0 = RFL(e0.x), d0 = RFL(e0.y), s1 = RFL(e1.x), d1 = RFL(e1.y), rem1 = RFL(e1.z), tok1 = RFL(e1.w);
+        uint32_t rem = RFL(e0.z), tokpos = RFL(e0.w);
         const bool last = (u + 1 == nunits);
         bool ok = s0 <= s1 && s1 <= n_src && d0 <= d1 && d1 <= nbytes && (d1 - d0) <= DEC_OUT_MAX;
         if (u == 0) ok = ok && s0 == 0 && d0 == 0 && rem == HB_IDX_AT_TOKEN;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         };
         stage(0u);
         uint32_t tok = 0;
-        if (rem != HB_IDX_AT_TOKEN) tok = src[tokpos];
+        if (rem != HB_IDX_AT_TOKEN) tok = RFL((uint32_t)src[tokpos]);
 #define INB(i) s_in[(uint32_t)((int)(i) + shw)]              /* stream byte at slice position i (inside the window) */
         uint32_t si = 0, di = 0;
         bool at_token = false;       // state when the unit stops
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 if (slow == 2) {
                     if (si >= slen) { ok = false; break; }
                     tokpos = s0 + si;
-                    tok = (si >= wlo && si < staged) ? INB(si) : g[si];
+                    tok = RFL((uint32_t)((si >= wlo && si < staged) ? INB(si) : g[si]));
                     si++;
                     rem = tok >> 4;
                     if (rem == 15u && !dec_read_ext(s_in, shw, wlo, staged, g, slen, si, rem, lane)) { ok = false; break; }
@@ -464,7 +467,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 if (rem > 0 || di == outlen) { at_token = false; done = true; break; }
                 // match phase
                 if (slen - si < 2) { ok = false; break; }             // also: block ends after literals -> serial decides
-                const uint32_t b0 = (si >= wlo && si < staged) ? INB(si) : g[si], b1 = (si + 1 >= wlo && si + 1 < staged) ? INB(si + 1) : g[si + 1];
+                const uint32_t b0 = RFL((uint32_t)((si >= wlo && si < staged) ? INB(si) : g[si]));
+                const uint32_t b1 = RFL((uint32_t)((si + 1 >= wlo && si + 1 < staged) ? INB(si + 1) : g[si + 1]));
                 const uint32_t offset = b0 | (b1 << 8);
                 si += 2;
                 uint32_t mlen = (tok & 15u) + 4u;
@@ -475,10 +479,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 // peek: a next token with a multi-byte match extension would come straight back from the window parser
                 // (highly compressible units are a handful of such tokens): stay on this path
                 if (si >= wlo && si + 4u <= staged && di < outlen) {
-                    const uint32_t t2 = INB(si), l2 = t2 >> 4;
+                    const uint32_t t2 = RFL((uint32_t)INB(si)), l2 = t2 >> 4;
                     if (l2 < 15u && (t2 & 15u) == 15u) {
                         const uint32_t op = si + 1u + l2;
-                        if (op + 3u <= staged && INB(op + 2u) == 255u) slow = 2;
+                        if (op + 3u <= staged && RFL((uint32_t)INB(op + 2u)) == 255u) slow = 2;
                     }
                 }
                 continue;
