@@ -731,19 +731,29 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
         if (t < 256) s_nf[t] = min(x, y);
         __syncthreads();
     }
-    const Agg tpre = tile_pre[blockIdx.x];
+    const Agg tpre = tile_pre[blockIdx.x];                            // (uniform address: scalar loads)
     const uint32_t tsuf = tile_suf[blockIdx.x];
+    // values read from LDS are wave-uniform here but arrive in vector registers: move them to scalar ones, or every
+    // address computation and copy loop below runs on the vector side under exec masks
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+    auto rfl_agg = [](const Agg &x) __attribute__((always_inline)) {
+        Agg r;
+        r.fixed = (int64_t)(((uint64_t)RFL((uint32_t)((uint64_t)x.fixed >> 32)) << 32) | RFL((uint32_t)(uint64_t)x.fixed));
+        r.F = RFL(x.F); r.E = RFL(x.E); r.has = RFL(x.has); r.pad = 0;
+        return r;
+    };
     uint8_t *index = nullptr;
     if (index_base_ext) index = index_base_ext;
     else if (frame_base && plan->index_off) index = frame_base + plan->index_off;
 
     for (uint32_t c = wave; c < cnt; c += NW) {
         const uint32_t ck = ck0 + c;
-        const ChunkDesc cd = s_desc[c];
+        ChunkDesc cd = s_desc[c];
+        cd.lead = RFL(cd.lead); cd.enc_len = RFL(cd.enc_len); cd.last_end = RFL(cd.last_end); cd.mcode0 = RFL(cd.mcode0);
         const uint32_t start = ck * HB_CHUNK;
         const uint32_t end = (uint32_t)min((uint64_t)start + HB_CHUNK, n);
-        const Agg P = agg_combine(tpre, c ? s[c - 1] : agg_identity());          // everything before this chunk
-        uint32_t NF = min(tsuf, (c + 1 < 256) ? s_nf[c + 1] : 0xFFFFFFFFu);       // next match after this chunk
+        const Agg P = agg_combine(tpre, c ? rfl_agg(s[c - 1]) : agg_identity()); // everything before this chunk
+        uint32_t NF = min(tsuf, (c + 1 < 256) ? RFL(s_nf[c + 1]) : 0xFFFFFFFFu);  // next match after this chunk
         if (NF == 0xFFFFFFFFu) NF = (uint32_t)n;                                  // ... or the end of the block
         const uint32_t a = P.has ? P.E : 0u;
         const uint64_t O = (uint64_t)agg_bytes(P);
