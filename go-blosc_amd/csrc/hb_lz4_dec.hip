@@ -649,7 +649,7 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
             // ---- one token the slow way (length extensions of any size, literal runs of any size) ----
             if (si < wpos || si >= wpos + wlen) refill(si);
             rel = (uint32_t)(si - wpos);
-            tok = s_win[wsh + rel];
+            tok = __builtin_amdgcn_readfirstlane((uint32_t)s_win[wsh + rel]);   // uniform, but from a vector load
             rel++;
             uint32_t ll = tok >> 4;
             if (ll == 15u) {
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(64) void k_dec_serial(const uint8_t *__restrict__ s
         }
         if (phase == 2) {
             if (n_src - si < 2) { err = 1; break; }
-            moff = (uint32_t)src[si] | ((uint32_t)src[si + 1] << 8);
+            moff = __builtin_amdgcn_readfirstlane((uint32_t)src[si] | ((uint32_t)src[si + 1] << 8));
             si += 2;
             if (moff == 0) { err = 1; break; }
             uint32_t ml = (tok & 15u) + 4u;
