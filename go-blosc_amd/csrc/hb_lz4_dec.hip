@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
         // wave-uniform values that come out of vector loads are moved to scalar registers: the compiler cannot know
         // they are uniform, and would otherwise run the whole state machine on the vector side under exec masks
-#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
         const uint32_t s0 = RFL(e0.x), d0 = RFL(e0.y), s1 = RFL(e1.x), d1 = RFL(e1.y), rem1 = RFL(e1.z), tok1 = RFL(e1.w);
         uint32_t rem = RFL(e0.z), tokpos = RFL(e0.w);
         const bool last = (u + 1 == nunits);

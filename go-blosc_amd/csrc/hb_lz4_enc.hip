@@ -735,7 +735,7 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
     const uint32_t tsuf = tile_suf[blockIdx.x];
     // values read from LDS are wave-uniform here but arrive in vector registers: move them to scalar ones, or every
     // address computation and copy loop below runs on the vector side under exec masks
-#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))     /* the builtin is int -> int: no sign extension later */
     auto rfl_agg = [](const Agg &x) __attribute__((always_inline)) {
         Agg r;
         r.fixed = (int64_t)(((uint64_t)RFL((uint32_t)((uint64_t)x.fixed >> 32)) << 32) | RFL((uint32_t)(uint64_t)x.fixed));
