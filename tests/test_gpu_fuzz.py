@@ -87,3 +87,33 @@ def test_frames_multi_entry_point(hb, O):
         f = outs[k].raw[: rcs[k]]
         assert hb.Decompress(f) == xs[k].tobytes()
         assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), xs[k])
+
+
+def test_random_shapes_round_trip_and_decode_with_the_reference_decoder(hb, O):
+    # seeded sweep over sizes (ragged, window-sized, multi-window, multi-tile), filters, typesizes and data textures:
+    # every frame must decode on the device to the input AND through the restated reference decoder
+    rng = np.random.default_rng(424242)
+    sizes = [1, 2, 3, 15, 16, 17, 63, 64, 65, 255, 256, 4095, 4096, 4097, 8191, 12288, 16384 * 3, 65536 + 13, 4096 * 4 * 33,
+             (1 << 20) + 4096 * 8, 4096 * 8 * 17]
+    sizes += [int(s) for s in rng.integers(1, 3 << 20, 40)]
+    checked = 0
+    for n in sizes:
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            x = rng.integers(0, 256, n, dtype=np.uint8)                               # incompressible
+        elif kind == 1:
+            x = np.zeros(n, np.uint8); x[rng.integers(0, n, max(1, n // 500))] = 7      # sparse
+        elif kind == 2:
+            x = np.repeat(rng.integers(0, 256, n // 37 + 1, dtype=np.uint8), 37)[:n].copy()   # runs
+        elif kind == 3:
+            x = O.synth(O.D_F32, n // 4 + 1).view(np.uint8)[:n].copy()
+        else:
+            x = np.tile(rng.integers(0, 4, 1000, dtype=np.uint8) * 64, n // 1000 + 1)[:n].copy()   # few-valued noise, period 1000
+        shuffle = int(rng.integers(0, 3))
+        ts = int(rng.choice([1, 2, 3, 4, 8, 16]))
+        opts = hb.OPT_INDEX_TRAILER if rng.integers(0, 4) else 0
+        f = hb.Compress(x.tobytes(), hb.LZ4, 5, shuffle, ts, opts=opts)
+        assert hb.Decompress(f) == x.tobytes(), (n, kind, shuffle, ts, opts)
+        assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), x), (n, kind, shuffle, ts, opts)
+        checked += 1
+    assert checked == len(sizes)
