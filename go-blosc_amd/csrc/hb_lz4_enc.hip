@@ -144,7 +144,7 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 // take literals from; a chunk without any match then stores its whole image).
 __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_t sh, const int len,
                                             uint8_t *s_out /* SOUT + 16 */, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */, uint32_t *s_st /* 8 words */,
-                                            ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const int lane) {
+                                            ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const bool keep_long, const int lane) {
     {
         {
             u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
@@ -332,6 +332,12 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             cand = hit ? cand : (uint32_t)p - 1u;
             unsigned long long mask = m_hit | m_rle;
             if (mask) {
+                // An entry whose candidate still matches 12 bytes or more is put BACK: repeated content then keeps pointing
+                // at its first occurrence instead of at the previous repeat, so a decoder never finds a chain of matches
+                // that each copy the one before (bitshuffled integers: 27 dependency rounds per 64 tokens otherwise, 5
+                // with this); the ratio does not move.  Not in the fused byte-shuffle kernels: their long matches are runs
+                // (offset 1), and the extra LDS write costs their step loop 3 %.
+                if (keep_long && hit && (xa | xb) == 0u) s_tab[h] = (uint16_t)cand;
                 // every lane extends its own match to at most 20 bytes, branch-free (two more dwords on each side, read
                 // on this path only): v_ffbl_b32 gives -1 for 0, so the first differing bit of the 16 bytes is
                 // min(ffbl(xa), 32 + min(ffbl(xb), 32 + min(ffbl(xc), 32 + min(ffbl(xd), 32))))
@@ -462,7 +468,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 // HBM; the caller guarantees n % 32 == 0 and a 16-byte aligned src.
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
-                                              uint32_t nchunks, int bits4) {
+                                              uint32_t nchunks, int bits4, int keep_long) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 ((u32x4 *)s_data)[2 * w + 1] = ob;
             }
         }
-        match_chunk(s_data, sh, len, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, lane);
+        match_chunk(s_data, sh, len, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, keep_long != 0, lane);
     }
 }
 
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             }
         }
         const uint32_t ck = j * nblk + b;
-        match_chunk(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, lane);
+        match_chunk(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, lane);
     }
 }
 
@@ -819,7 +825,9 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
             }
         } else {
             const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;
-            hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks, a.fused_bits);
+            // byte-shuffled frames keep the fused kernels' table policy, fused or not (identical frames either way)
+            hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks, a.fused_bits,
+                               (a.frame && a.shuffle == HB_SHUFFLE && a.typesize > 1) ? 0 : 1);
         }
         hb_prof_end(s);
         hb_prof_begin("k_tiles", s);
