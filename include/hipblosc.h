@@ -123,7 +123,10 @@ size_t  hb_lz4_decompress_workspace(size_t n_out);
 int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
                         void *d_index, size_t index_cap,
                         void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
-/* async; d_index/index_bytes optional (NULL/0 -> serial single-wavefront decode) */
+/* async; d_index/index_bytes optional (NULL/0 -> serial single-wavefront decode).
+ * All `_dev` entry points load with 16-byte vectors: a source buffer may be READ up to 15 bytes past its last byte
+ * (never written), so it must not end exactly at the end of a device allocation's last page -- hipMalloc'd buffers
+ * with >= 16 bytes of slack, or any sub-range of a larger allocation, are fine. */
 int hb_lz4_decompress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
                           const void *d_index, size_t index_bytes,
                           void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
@@ -151,8 +154,9 @@ size_t  hb_decompress_frame_workspace(size_t n_out);
 int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap,
                           int codec, int level, int shuffle, int typesize, unsigned opts,
                           void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
-/* `n` = bytes available at d_frame (>= cbytes; may include the trailer).  nbytes_hint = expected decoded size
- * (cap of d_dst); the header is parsed on the device, no host round trip. */
+/* `n` = bytes available at d_frame (>= cbytes; may include the trailer); cap = room at d_dst.  The 16 header bytes are
+ * read back to the host first (one small D2H + stream sync: the launch shapes depend on them), so header errors come
+ * back as the return value; everything after that is asynchronous and reports through *d_result. */
 int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t cap,
                             int typesize_override,
                             void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
