@@ -399,7 +399,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 while (mask) {
                     const int j = __builtin_ctzll(mask);
                     int mlj = (int)__builtin_amdgcn_readlane(ml, j);
-                    if ((lmask >> j) & 1ull) {             // still matching after 12 bytes: 256 bytes per step
+                    if ((lmask >> j) & 1ull) {             // still matching after 20 bytes: 256 bytes per step
                         const int mp = pos + j, mc = (int)__builtin_amdgcn_readlane(cand, j);
                         const int maxl = mend_max - mp;
                         for (;;) {
