@@ -20,8 +20,8 @@
 //              prefix sum -> every lane writes its own token / extension / literals / offset into a 768-byte staging
 //              buffer, which is drained to the record with 16-byte stores after every flush (a 4 KiB record image
 //              would cost the occupancy the kernel lives on: time x resident waves is constant up to ~16 waves per
-//              CU; 6.5 KiB of LDS and 80 VGPRs give 24).  The emission state lives in LDS between flushes.  After 4
-//              steps without a hit the scan strides over 64-byte gaps (LZ4's skip acceleration).  Matches never
+//              CU; 6.5 KiB of LDS and 80 VGPRs give 24).  The emission state lives in LDS between flushes.  Every
+//              step without a hit widens the stride by 64 bytes (LZ4's skip acceleration).  Matches never
 //              leave the chunk; the last 5 bytes of a chunk stay literals and no match starts in its last 12 (LZ4
 //              end-of-block rules, applied per chunk so the very last chunk satisfies them).
 //              Record:  [lead literals][rest of sequence 0][sequence 1]...[sequence m-1]  (+ [trailing literals] when fused)
@@ -437,7 +437,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             } else {
                 miss++;
             }
-            const int nxt = pos + 64 + ((miss >> 2) << 6);
+            const int nxt = pos + 64 + (miss << 6);             // every step without a hit widens the stride by 64 bytes
             pos = anchor > nxt ? anchor : nxt;
         }
         while (nq > 0) flush();
