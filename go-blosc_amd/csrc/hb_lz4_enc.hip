@@ -312,7 +312,8 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t before = wave_shr1(vb, prevb);
             const uint32_t b4 = vb * 0x01010101u;
             const unsigned long long m_first = pos > 0 ? ~0ull : ~1ull;            // p >= 1
-            const unsigned long long m_eqprev = hb_ballot(before == vb);           // bit l: data[pos+l] == data[pos+l-1]
+            // bit l: data[pos+l] == data[pos+l-1]; positions past the end of the chunk hold whatever was in LDS: masked out
+            const unsigned long long m_eqprev = hb_ballot(before == vb) & (len - pos >= 64 ? ~0ull : ((1ull << (len - pos)) - 1ull));
             const unsigned long long m_rle = hb_ballot(valid) & hb_ballot(v == b4) & m_eqprev & m_first;
             const bool rle = valid && (pos > 0 || lane > 0) && v == b4 && before == vb;
             const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
@@ -358,7 +359,8 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 if (lmask & m_rle & ~m_hit) {
                     // a run: the offset-1 match is the rest of the run, and the wave already knows where runs end as far
                     // as this window goes -- only a run that leaves the window needs the cooperative extension
-                    const uint32_t run = (uint32_t)__builtin_ctzll(~(m_eqprev >> lane));
+                    const unsigned long long nrun = ~(m_eqprev >> lane);           // (0 for lane 0 of a window that is one run)
+                    const uint32_t run = nrun ? (uint32_t)__builtin_ctzll(nrun) : 64u;
                     // a run that reaches the end of the window stops there if the next byte differs (bitshuffled data has
                     // runs that end on 32-byte window boundaries all the time)
                     const bool endstop = data[pos + 64] != data[pos + 63];
@@ -817,14 +819,24 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
         hb_prof_begin(a.fused_ts ? "k_match_fused" : "k_match", s);
         if (a.fused_ts) {
             const uint32_t nblk = L.nchunks / (uint32_t)a.fused_ts;
-            const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;     // multiple of 8 when capped
+            // one chunk per workgroup for small frames; beyond that each workgroup makes `typesize` passes where possible -- it
+            // then meets every plane exactly once (planes differ 10x in cost) and the workgroups of a block drift apart the
+            // least (they share the source lines in L2): measured 1.99 ms with 16384 workgroups, 1.79 ms with 65536,
+            // 3.06 ms with one chunk per workgroup (1 GiB, typesize 4).  A capped grid is a multiple of 8 * typesize.
+            unsigned grid = L.nchunks;
+            if (grid > 256u * 64u) {
+                const unsigned gran = 8u * (unsigned)a.fused_ts;
+                grid = nblk / gran * gran;
+                if (grid < 256u * 64u) grid = 256u * 64u;
+                if (grid > 256u * 256u) grid = 256u * 256u;
+            }
             switch (a.fused_ts) {
             case 2: hipLaunchKernelGGL(k_match_fused<2>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
             case 4: hipLaunchKernelGGL(k_match_fused<4>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
             default: hipLaunchKernelGGL(k_match_fused<8>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
             }
         } else {
-            const unsigned grid = L.nchunks < 256u * 64u ? L.nchunks : 256u * 64u;
+            const unsigned grid = L.nchunks < 256u * 256u ? L.nchunks : 256u * 256u;
             // byte-shuffled frames keep the fused kernels' table policy, fused or not (identical frames either way)
             hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks, a.fused_bits,
                                (a.frame && a.shuffle == HB_SHUFFLE && a.typesize > 1) ? 0 : 1);

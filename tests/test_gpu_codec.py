@@ -466,3 +466,40 @@ def test_fused_unshuffle_in_decoder_equals_separate_pass(hb, O, ts):
             assert y == ref
     except (hb.ErrDecompressionFailed, hb.ErrSizeMismatch, hb.ErrInvalidData):
         pass
+
+
+def test_window_that_is_one_run_is_one_match(hb, O):
+    # Skip acceleration can land a 64-position window in the middle of a long run; the run then fills the whole window
+    # ("equals the byte before" mask all ones, lane 0 included).  That case once took count-trailing-zeros of 0 and cut
+    # the run into 31-byte matches, with a result that depended on what LDS held past the end of the chunk.
+    rng = np.random.default_rng(5)
+    for head in (2300, 1000, 3100, 517):
+        x = np.concatenate([rng.integers(0, 256, head, dtype=np.uint8), np.zeros(4096 - head, np.uint8)])
+        x = np.tile(x, 64)                                      # 64 chunks, so workgroups also see used LDS
+        fr = [hb.Compress(x.tobytes(), hb.LZ4, 5, hb.NoShuffle, 1, opts=hb.OPT_INDEX_TRAILER) for _ in range(4)]
+        assert all(f == fr[0] for f in fr), "encoder output differs between runs"
+        h = hb.ParseHeader(fr[0])
+        # per chunk: a literal run (the random head, plus whatever of the run the growing stride jumped over) and one
+        # or two matches -- not a string of 31-byte ones
+        c = fr[0][16:h.NBytesComp]
+        i = nseq = 0
+        while i < len(c):
+            t = c[i]; i += 1
+            lit = t >> 4
+            if lit == 15:
+                while True:
+                    b = c[i]; i += 1; lit += b
+                    if b != 255:
+                        break
+            i += lit
+            if i >= len(c):
+                break
+            i += 2
+            if (t & 15) == 15:
+                while c[i] == 255:
+                    i += 1
+                i += 1
+            nseq += 1
+        assert nseq <= 64 * 3, (head, nseq)
+        assert hb.Decompress(fr[0]) == x.tobytes()
+        assert np.array_equal(O.decompress_frame(np.frombuffer(fr[0], np.uint8)), x)
