@@ -8,7 +8,7 @@
 //              the image straight from the un-filtered source: byte shuffle fused, no filtered buffer in HBM).
 //              Every step the 64 lanes look at 64 consecutive positions: 12 bytes at the position and 12 at the
 //              table candidate (aligned dwords + v_alignbyte: a misaligned ds_read_b32 is replayed), hash of the first
-//              4, probe / insert into a 512-entry u16 table in LDS, verify, and -- when any lane hit -- a branch-free
+//              4, probe / insert into a 256-entry u16 table in LDS, verify, and -- when any lane hit -- a branch-free
 //              extension to at most 20 bytes.  Positions inside a run of equal 4-grams are not inserted, so the table
 //              keeps run STARTS (a candidate at the end of a run cannot be extended), and such positions fall back to
 //              the offset-1 candidate, whose length comes from the wave-wide "equals the byte before" mask as far
@@ -20,7 +20,7 @@
 //              prefix sum -> every lane writes its own token / extension / literals / offset into a 768-byte staging
 //              buffer, which is drained to the record with 16-byte stores after every flush (a 4 KiB record image
 //              would cost the occupancy the kernel lives on: time x resident waves is constant up to ~16 waves per
-//              CU; 6.5 KiB of LDS and 80 VGPRs give 24).  The emission state lives in LDS between flushes.  Every
+//              CU; 6 KiB of LDS and 64 VGPRs give 26).  The emission state lives in LDS between flushes.  Every
 //              step without a hit widens the stride by 64 bytes (LZ4's skip acceleration).  Matches never
 //              leave the chunk; the last 5 bytes of a chunk stay literals and no match starts in its last 12 (LZ4
 //              end-of-block rules, applied per chunk so the very last chunk satisfies them).
@@ -40,7 +40,7 @@
 // bytes of the source read a second time by k_stitch; see DESIGN.md.
 #include "hb_lz4.h"
 
-#define HLOG 9
+#define HLOG 8
 #define HSIZE (1u << HLOG)
 #define LITCAP 16u          // literal runs up to this long are copied by the owning lane, longer ones by the wave
 
