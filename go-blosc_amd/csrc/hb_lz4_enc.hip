@@ -42,7 +42,7 @@
 
 #define HLOG 8
 #define HSIZE (1u << HLOG)
-#define LITCAP 16u          // literal runs up to this long are copied by the owning lane, longer ones by the wave
+#define LITCAP 32u          // literal runs up to this long are copied by the owning lane, longer ones by the wave
 
 struct __attribute__((aligned(16))) ChunkDesc {
     uint32_t lead;      // literals before the first match (chunk-relative)
