@@ -751,13 +751,14 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
         // a few units per workgroup (measured on 1 GiB: 16384 workgroups 1.84 ms, 65536 1.70 ms, 131072 2.09 ms, one unit per
         // workgroup 3.56 ms); odd when capped, so that the scrambled order rotates the mix of planes from pass to pass
         unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 256u + 1u ? units : 256u * 256u + 1u));
-        if (a.fused_unshuffle_ts && units > 256u * 64u) {
-            // fused un-shuffle: `typesize` passes per workgroup where possible (it then meets every plane once), and a
-            // multiple of 8 * typesize (see the unit order in the kernel)
+        if (a.fused_unshuffle_ts && units > 256u * 16u) {
+            // fused un-shuffle, beyond 16 MiB: `typesize` passes per workgroup where possible (it then meets every plane
+            // once), and a multiple of 8 * typesize (see the unit order in the kernel)
             const unsigned gran = 8u * (unsigned)a.fused_unshuffle_ts;
-            grid = (unsigned)(units / (uint64_t)a.fused_unshuffle_ts) / gran * gran;
-            if (grid < 256u * 64u) grid = 256u * 64u;
-            if (grid > 256u * 256u) grid = 256u * 256u;
+            unsigned g2 = (unsigned)(units / (uint64_t)a.fused_unshuffle_ts) / gran * gran;
+            if (units > 256u * 64u && g2 < 256u * 64u) g2 = 256u * 64u;
+            if (g2 > 256u * 256u) g2 = 256u * 256u;
+            if (g2) grid = g2;
         }
         hb_prof_begin("k_dec_indexed", s);
         hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan,

@@ -823,12 +823,13 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
             // then meets every plane exactly once (planes differ 10x in cost) and the workgroups of a block drift apart the
             // least (they share the source lines in L2): measured 1.99 ms with 16384 workgroups, 1.79 ms with 65536,
             // 3.06 ms with one chunk per workgroup (1 GiB, typesize 4).  A capped grid is a multiple of 8 * typesize.
-            unsigned grid = L.nchunks;
-            if (grid > 256u * 64u) {
+            unsigned grid = L.nchunks;                                   // up to 16 MiB: latency first, one chunk per workgroup
+            if (grid > 256u * 16u) {
                 const unsigned gran = 8u * (unsigned)a.fused_ts;
-                grid = nblk / gran * gran;
-                if (grid < 256u * 64u) grid = 256u * 64u;
+                grid = nblk / gran * gran;                               // `typesize` passes
+                if (L.nchunks > 256u * 64u && grid < 256u * 64u) grid = 256u * 64u;   // 64 - 256 MiB: at least 16384 workgroups
                 if (grid > 256u * 256u) grid = 256u * 256u;
+                if (grid == 0) grid = L.nchunks;
             }
             switch (a.fused_ts) {
             case 2: hipLaunchKernelGGL(k_match_fused<2>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
