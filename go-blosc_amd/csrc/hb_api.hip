@@ -4,6 +4,7 @@
 #include "hb_common.h"
 #include "hb_lz4.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <algorithm>
@@ -73,7 +74,8 @@ int select_device(int device) {
     return HB_OK;
 }
 
-bool g_no_dec_fusion = false;              // hb_debug_decode_fusion(0): A/B switch for bench / tests
+std::atomic<bool> g_no_dec_fusion{false};  // hb_debug_decode_fusion(0): A/B switch for bench / tests (atomic: any thread may flip it)
+std::atomic<unsigned> g_plane_mask{~0u};   // hb_debug_plane_mask(): timing-only switch, see hipblosc.h
 thread_local unsigned g_last_flags = 0;   // hb_result.flags of the last host-pointer call on this thread
 
 bool overlap(const void *a, size_t na, const void *b, size_t nb) {
@@ -82,6 +84,8 @@ bool overlap(const void *a, size_t na, const void *b, size_t nb) {
 }
 
 }  // namespace
+
+unsigned hb_dbg_plane_mask() { return g_plane_mask.load(std::memory_order_relaxed); }
 
 // ---- stage timing -------------------------------------------------------------------------
 namespace {
@@ -141,6 +145,7 @@ void hb_shutdown(void) {
 const char *hb_version(void) { return HB_VERSION_STRING; }
 unsigned hb_last_result_flags(void) { return g_last_flags; }
 void hb_debug_decode_fusion(int on) { g_no_dec_fusion = !on; }
+void hb_debug_plane_mask(unsigned mask) { g_plane_mask = mask; }
 
 const char *hb_strerror(int code) {
     switch (code) {

@@ -116,6 +116,8 @@ __device__ __forceinline__ void bitshuffle4_window(const u32x4 a, const u32x4 b,
 void hb_prof_begin(const char *stage, hipStream_t s);   // no-ops unless hb_profile_enable(1)
 void hb_prof_end(hipStream_t s);
 
+unsigned hb_dbg_plane_mask();                            // hb_debug_plane_mask(): byte planes the fused LZ4 kernels work on (timing only)
+
 // ---- internal launch API shared between translation units ----
 int hb_launch_filter(int op, uint8_t *d_dst, const uint8_t *d_src, size_t n, int typesize, hipStream_t s);
 // same, but every kernel returns immediately unless *gate != 0 (gate is read on the device)

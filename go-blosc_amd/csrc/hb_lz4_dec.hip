@@ -55,6 +55,9 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
     const uint64_t nunits = h[2];
     if (nunits == 0 || HB_IDX_HDR_BYTES + (nunits + 1) * HB_IDX_ENTRY > index_bytes) return;
     if (h[4] != n_src || h[5] > cap) return;
+    // one unit per HB_CHUNK bytes of output, exactly: the launch shape and the fused un-shuffle's unit order are derived from
+    // the header's nbytes, so an index with any other unit geometry (even a self-consistent one) is not used
+    if (h[3] != HB_CHUNK || nunits != ((uint64_t)h[5] + HB_CHUNK - 1) / HB_CHUNK) return;
     plan->nunits = (uint32_t)nunits;
     plan->nbytes = h[5];
     uint32_t P = (uint32_t)nunits / 4u + 1u;                 // about a quarter turn per step (next byte plane of a shuffled frame)
@@ -330,7 +333,7 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
-                                                    DecPlan *plan, int bun4, int ush) {
+                                                    DecPlan *plan, int bun4, int ush, uint32_t plane_mask) {
     // ush != 0: the frame was byte-shuffled with typesize `ush` and has only whole planes of whole chunks; the un-shuffle is
     // fused: a unit is a piece of ONE byte plane j, and its byte i goes straight to dst[(e0 + i) * ush + j] with byte
     // stores (64 lanes cover 64 * ush bytes; the other planes' waves fill in the rest of those lines, and the
@@ -353,7 +356,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     const uint32_t P = plan->stride;                        // computed once by k_dec_plan
     for (uint32_t it = blockIdx.x; it < nunits; it += gridDim.x) {
         uint32_t u = (uint32_t)(((uint64_t)it * P) % nunits);
-        if (ush && nunits % (uint32_t)ush == 0u) {
+        // (the plane-rotating order below visits every unit exactly once only when the grid is a multiple of 8 * ush or
+        // covers all units in one pass; any other launch shape keeps the plain bijection above)
+        if (ush && nunits % (uint32_t)ush == 0u && (gridDim.x % (8u * (uint32_t)ush) == 0u || gridDim.x >= nunits)) {
             // fused un-shuffle: the `ush` units that make up one 4096-element block write interleaved bytes of the same
             // lines, so they get workgroup ids that are equal mod 8 (same XCD under round-robin placement: the
             // partial lines meet in one L2) and run close in time; the plane rotates with the pass (planes differ in
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
                 b = grp * 8u + k % nb; j = k / nb;
             }
             u = j * nblk + b;
+            if (!((plane_mask >> j) & 1u)) continue;            // hb_debug_plane_mask: per-plane timing
         }
         const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
         // wave-uniform values that come out of vector loads are moved to scalar registers: the compiler cannot know
@@ -391,7 +397,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         if (rem != HB_IDX_AT_TOKEN && rem >= outlen) {
             const uint32_t left = rem - outlen;
             bool fine = slen == outlen;
-            if (last) fine = fine && left == 0; else fine = fine && rem1 == left && tok1 == tokpos;
+            // a block that ends inside/after a literal run is accepted only if that token announces no match
+            // (UncompressBlock: si == len(src) && matchNibble == 0; oracle/blosc_oracle.c ob_lz4_decompress) -- else the serial decoder decides
+            if (last) fine = fine && left == 0 && (RFL((uint32_t)src[tokpos]) & 15u) == 0u; else fine = fine && rem1 == left && tok1 == tokpos;
             if (!fine) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
             if (ush) {                                          // wide loads (any alignment) into the image, then the strided stores
                 for (uint32_t i = lane * 16u; i < outlen; i += 1024u) {
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         // end-state check against the next entry
         if (ok) {
             ok = (si == slen) && (di == outlen);
-            if (last) ok = ok && (at_token || rem == 0);
+            if (last) ok = ok && (at_token || (rem == 0 && (tok & 15u) == 0u));   // ends after literals: the token must announce no match
             else if (at_token) ok = ok && rem1 == HB_IDX_AT_TOKEN;
             else ok = ok && rem1 == rem && tok1 == tokpos;
         }
@@ -762,7 +770,7 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
         }
         hb_prof_begin("k_dec_indexed", s);
         hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan,
-                           a.fused_bitunshuffle4, a.fused_unshuffle_ts);
+                           a.fused_bitunshuffle4, a.fused_unshuffle_ts, hb_dbg_plane_mask());
         hb_prof_end(s);
     }
     // with a fused un-filter the indexed decoder wrote FINAL bytes to a.dst; the serial decoder (if it has to run)

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 // only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
 template <int TS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
-                                                    uint8_t *__restrict__ records, uint32_t nblk) {
+                                                    uint8_t *__restrict__ records, uint32_t nblk, uint32_t plane_mask) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
@@ -529,6 +529,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             const uint32_t nb = nblk - grp * 8u;
             b = grp * 8u + k % nb; j = k / nb;
         }
+        if (!((plane_mask >> j) & 1u)) continue;           // hb_debug_plane_mask: per-plane timing
         const uint64_t e0 = (uint64_t)b * HB_CHUNK;        // first element of the block
         wave_sync();
         // all loads of a batch are issued before the first use: one HBM round trip per 16 vectors, not 16
@@ -832,9 +833,9 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
                 if (grid == 0) grid = L.nchunks;
             }
             switch (a.fused_ts) {
-            case 2: hipLaunchKernelGGL(k_match_fused<2>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
-            case 4: hipLaunchKernelGGL(k_match_fused<4>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
-            default: hipLaunchKernelGGL(k_match_fused<8>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk); break;
+            case 2: hipLaunchKernelGGL(k_match_fused<2>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask()); break;
+            case 4: hipLaunchKernelGGL(k_match_fused<4>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask()); break;
+            default: hipLaunchKernelGGL(k_match_fused<8>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask()); break;
             }
         } else {
             const unsigned grid = L.nchunks < 256u * 256u ? L.nchunks : 256u * 256u;

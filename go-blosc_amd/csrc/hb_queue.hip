@@ -9,6 +9,7 @@
 #include "hb_lz4.h"
 
 #include <vector>
+#include <utility>
 #include <new>
 
 extern "C" {
@@ -39,6 +40,8 @@ struct hb_queue {
     size_t max_n = 0, in_bytes = 0, out_bytes = 0, work_bytes = 0;
     std::vector<Slot> slots;
     int64_t next_ticket = 0;
+    // results of tickets whose slot was re-used before they were waited for: {ticket, rc}, the newest 4 * depth of them
+    std::vector<std::pair<int64_t, int64_t>> kept;
 };
 
 namespace {
@@ -72,7 +75,11 @@ void finish(hb_queue *q, Slot &s) {
 Slot *take_slot(hb_queue *q, int64_t *ticket) {
     *ticket = q->next_ticket++;
     Slot &s = q->slots[(size_t)(*ticket % (int64_t)q->slots.size())];
-    finish(q, s);                        // all slots in flight: the oldest one is completed first (result kept)
+    finish(q, s);                        // all slots in flight: the oldest one is completed first ...
+    if (s.state == SLOT_DONE && s.ticket >= 0) {   // ... and its result is kept for its hb_queue_wait (the data is already in its dst)
+        if (q->kept.size() >= 4 * q->slots.size()) q->kept.erase(q->kept.begin());
+        q->kept.push_back({s.ticket, s.rc});
+    }
     return &s;
 }
 
@@ -89,7 +96,8 @@ hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes) {
     q->device = device;
     q->max_n = max_nbytes;
     const size_t fb = hb_frame_bound(max_nbytes) + 64;
-    q->in_bytes = fb;                                       // compress: the input (<= max_n); decompress: a frame (<= bound)
+    q->in_bytes = fb;                                       // compress: the input (<= max_n); decompress: a frame (<= bound);
+                                                            // allocated with 64 bytes of slack: the kernels' 16-byte loads may read past the end
     q->out_bytes = fb;                                      // compress: the frame; decompress: the output (<= max_n)
     q->work_bytes = hb_compress_frame_workspace(max_nbytes);
     if (hb_decompress_frame_workspace(max_nbytes) > q->work_bytes) q->work_bytes = hb_decompress_frame_workspace(max_nbytes);
@@ -97,7 +105,7 @@ hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes) {
     bool ok = true;
     for (auto &s : q->slots) {
         ok = ok && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipMalloc((void **)&s.d_in, q->in_bytes) == hipSuccess;
+        ok = ok && hipMalloc((void **)&s.d_in, q->in_bytes + 64) == hipSuccess;
         ok = ok && hipMalloc((void **)&s.d_out, q->out_bytes) == hipSuccess;
         ok = ok && hipMalloc((void **)&s.d_work, q->work_bytes) == hipSuccess;
         ok = ok && hipMalloc((void **)&s.d_res, sizeof(hb_result)) == hipSuccess;
@@ -164,7 +172,12 @@ int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst,
 int64_t hb_queue_wait(hb_queue *q, int64_t ticket) {
     if (!q || ticket < 0 || ticket >= q->next_ticket) return HB_ERR_BAD_ARG;
     Slot &s = q->slots[(size_t)(ticket % (int64_t)q->slots.size())];
-    if (s.ticket != ticket || s.state == SLOT_FREE) return HB_ERR_BAD_ARG;    // already waited for, or overwritten
+    if (s.ticket != ticket) {                                                 // slot re-used since: the result may have been kept
+        for (size_t i = 0; i < q->kept.size(); i++)
+            if (q->kept[i].first == ticket) { const int64_t rc = q->kept[i].second; q->kept.erase(q->kept.begin() + (long)i); return rc; }
+        return HB_ERR_BAD_ARG;                                                // already waited for, or too old
+    }
+    if (s.state == SLOT_FREE) return HB_ERR_BAD_ARG;                          // already waited for
     finish(q, s);
     s.state = SLOT_FREE;
     return s.rc;

@@ -27,6 +27,7 @@ struct ZstdApi {
     unsigned (*is_error)(size_t);
     size_t (*frame_csize)(const void *, size_t);
     unsigned long long (*frame_content)(const void *, size_t);
+    int (*error_code)(size_t);           // ZSTD_getErrorCode (optional)
 };
 
 const ZstdApi *zstd_api() {
@@ -46,6 +47,7 @@ const ZstdApi *zstd_api() {
         api.is_error = (decltype(api.is_error))dlsym(h, "ZSTD_isError");
         api.frame_csize = (decltype(api.frame_csize))dlsym(h, "ZSTD_findFrameCompressedSize");
         api.frame_content = (decltype(api.frame_content))dlsym(h, "ZSTD_getFrameContentSize");
+        api.error_code = (decltype(api.error_code))dlsym(h, "ZSTD_getErrorCode");
         ok = api.compress && api.bound && api.decompress && api.is_error && api.frame_csize && api.frame_content;
     });
     return ok ? &api : nullptr;
@@ -220,7 +222,9 @@ int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *ds
         const size_t c = z->frame_csize(p + at, plen - at);
         const unsigned long long d = z->is_error(c) ? ~0ull : z->frame_content(p + at, plen - at);
         if (z->is_error(c) || d >= 0xFFFFFFFFFFFFFFFEull) { table_ok = false; break; }     // unknown size / not a frame
-        if (d > n - out) { rc = HB_ERR_DECOMPRESSION_FAILED; break; }                       // would overflow expectedSize
+        // more content than NBytesOrig: the reference's DecodeAll grows its buffer and the frame layer then reports
+        // ErrSizeMismatch (blosc.go:429-431), not a codec error
+        if (d > n - out) { rc = HB_ERR_SIZE_MISMATCH; break; }
         tasks.push_back(Task{at, c, out, (size_t)d});
         at += c; out += (size_t)d;
     }
@@ -245,7 +249,9 @@ int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *ds
         got = out;
     } else if (!rc) {                                                 // no usable frame table: one call, as DecodeAll
         const size_t r = z->decompress(target, n, p, plen);
-        if (z->is_error(r)) rc = HB_ERR_DECOMPRESSION_FAILED; else got = r;
+        if (z->is_error(r))                                           // 70 = ZSTD_error_dstSize_tooSmall: decodes, but to more than NBytesOrig
+            rc = (z->error_code && z->error_code(r) == 70) ? HB_ERR_SIZE_MISMATCH : HB_ERR_DECOMPRESSION_FAILED;
+        else got = r;
     }
     if (!rc && got != n) rc = HB_ERR_SIZE_MISMATCH;                   // blosc.go:429-431
     if (!rc && unf >= 0 && n) {

@@ -88,7 +88,7 @@ EXPORTS = [
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
-    "hb_debug_decode_fusion", "hb_queue_create", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
+    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_queue_create", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
 
 
@@ -139,7 +139,7 @@ def lib():
             "hb_last_result_flags": (u32, []),
             "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
             "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),
-            "hb_debug_decode_fusion": (None, [i32]),
+            "hb_debug_decode_fusion": (None, [i32]), "hb_debug_plane_mask": (None, [u32]),
             "hb_queue_create": (vp, [i32, i32, sz]), "hb_queue_destroy": (None, [vp]),
             "hb_queue_compress": (i64, [vp, vp, sz, vp, sz, i32, i32, i32, i32, u32]),
             "hb_queue_decompress": (i64, [vp, vp, sz, vp, sz, i32]),

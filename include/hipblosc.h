@@ -94,6 +94,9 @@ unsigned    hb_last_result_flags(void);    /* hb_result.flags of the last host-p
 void        hb_debug_decode_fusion(int on); /* A/B switch for bench / tests (default on): 0 = decode byte-shuffled frames with a
                                               separate un-shuffle pass instead of the decoder's fused byte-strided stores */
 
+void        hb_debug_plane_mask(unsigned mask); /* TIMING ONLY (tools/plane_times.py): bit j clear = the fused shuffle+LZ4 kernels skip byte
+                                              plane j of every element block, so a frame is garbage; default ~0u = all planes */
+
 /* stage timing for the bench harness (single-threaded use): with enable(1) every kernel stage launched by the
  * `_dev` entry points is bracketed by HIP events on its stream; get(i) returns the stage name and its ms. */
 int         hb_profile_enable(int on);
@@ -183,7 +186,9 @@ int64_t hb_queue_compress(hb_queue *q, const void *src, size_t n, void *dst, siz
                           int codec, int level, int shuffle, int typesize, unsigned opts);
 int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst, size_t cap, int typesize_override);
 /* blocks until the frame is in dst; returns what hb_compress_frame / hb_decompress_frame would have returned.
- * Tickets may be waited for in any order, each once, and not later than `depth` submissions after their own. */
+ * Tickets may be waited for in any order, each once.  A ticket whose slot has been re-used by a later submission (more
+ * than `depth` submissions ago) was finished at that moment -- its data is in its dst -- and its return value is kept
+ * for the newest 4 * depth such tickets; older ones answer HB_ERR_BAD_ARG. */
 int64_t hb_queue_wait(hb_queue *q, int64_t ticket);
 
 #ifdef __cplusplus

@@ -11,8 +11,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/b
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY --output-format csv -d $O/sq -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/sq.log 2>&1
+# second SQ pass (8 slots per pass): where waves are parked, LDS behaviour, vector-memory instruction mix
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $O/sq2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/sq2.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq3 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/sq3.log 2>&1 || true
 cd $R
 python3 profiles/summarize.py traffic $O/fetch $O/write $O/traffic.json "bench.py default: 1024 MiB D-f32 frame, Shuffle1 ts=4 + LZ4, index trailer, 1 GPU (MI355X)"
 python3 profiles/summarize.py counters $O/sq $O/sq.csv
+python3 profiles/summarize.py counters $O/sq2 $O/sq2.csv
+python3 profiles/summarize.py counters $O/sq3 $O/sq3.csv || true
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 tail -1 $O/trace.log | cut -c1-300
