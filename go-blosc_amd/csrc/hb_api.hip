@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <thread>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -22,10 +23,17 @@ void do_init() {
     g_ndev = n;
 }
 
-// ---- grow-only cache of device buffers, per device (hipMalloc/hipFree cost milliseconds) ----
+// ---- cache of device buffers, per device (hipMalloc/hipFree cost milliseconds), bounded: what is idle beyond
+// g_pool_limit bytes is given back to the driver, largest first -- one frame with a hostile header (nbytes ~ 4 GiB)
+// must not pin gigabytes of HBM until hb_shutdown().  Default 12 GiB (a 1 GiB frame keeps ~5.2 GiB of scratch warm);
+// HIPBLOSC_POOL_MAX_MB or hb_pool_limit() change it. ----
 struct Buf { void *p; size_t bytes; int dev; };
 std::mutex g_pool_mu;
 std::vector<Buf> g_free;
+size_t g_pool_limit = [] {
+    const char *e = getenv("HIPBLOSC_POOL_MAX_MB");
+    return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)12 << 30;
+}();
 
 void *pool_get(int dev, size_t bytes, size_t *got) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -47,10 +55,27 @@ void *pool_get(int dev, size_t bytes, size_t *got) {
     *got = bytes;
     return p;
 }
+void pool_trim_locked(size_t keep) {        // g_pool_mu held; the buffers are idle: no kernel uses them (callers synchronise first)
+    for (;;) {
+        size_t total = 0; int big = -1;
+        for (int i = 0; i < (int)g_free.size(); i++) {
+            total += g_free[i].bytes;
+            if (big < 0 || g_free[i].bytes > g_free[big].bytes) big = i;
+        }
+        if (total <= keep || big < 0) return;
+        const Buf b = g_free[big];
+        g_free.erase(g_free.begin() + big);
+        int cur = -1;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != b.dev;
+        if (!sw || hipSetDevice(b.dev) == hipSuccess) (void)hipFree(b.p);
+        if (sw) (void)hipSetDevice(cur);
+    }
+}
 void pool_put(int dev, void *p, size_t bytes) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
     g_free.push_back(Buf{p, bytes, dev});
+    pool_trim_locked(g_pool_limit);
 }
 
 struct Scratch {     // RAII over pool buffers for one host-API call
@@ -90,38 +115,51 @@ unsigned hb_dbg_plane_mask() { return g_plane_mask.load(std::memory_order_relaxe
 // ---- stage timing -------------------------------------------------------------------------
 namespace {
 struct ProfRec { const char *name; hipEvent_t a, b; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};        // off: one relaxed load per kernel launch, nothing else
+std::mutex g_prof_mu;                      // the log itself (bench use is single-threaded; other threads must not corrupt it)
 std::vector<ProfRec> g_prof;
+thread_local int g_prof_open = -1;         // index of this thread's open stage
 }
 void hb_prof_begin(const char *stage, hipStream_t s) {
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
     ProfRec r{stage, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_open = (int)g_prof.size();
     g_prof.push_back(r);
 }
 void hb_prof_end(hipStream_t s) {
-    if (!g_prof_on || g_prof.empty()) return;
-    (void)hipEventRecord(g_prof.back().b, s);
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_open < 0 || g_prof_open >= (int)g_prof.size()) return;
+    (void)hipEventRecord(g_prof[(size_t)g_prof_open].b, s);
+    g_prof_open = -1;
 }
 
 extern "C" {
 
 // bench-only: single-threaded use.  enable(1) clears the log and starts recording one (stage, ms) per kernel launch.
 int hb_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     g_prof_on = on != 0;
     return HB_OK;
 }
-int hb_profile_count(void) { return (int)g_prof.size(); }
+int hb_profile_count(void) { std::lock_guard<std::mutex> lk(g_prof_mu); return (int)g_prof.size(); }
 // returns the stage name (static string) and its duration in ms; synchronises on the stage's end event
 const char *hb_profile_get(int i, float *ms) {
-    if (i < 0 || i >= (int)g_prof.size()) return nullptr;
+    ProfRec r;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (i < 0 || i >= (int)g_prof.size()) return nullptr;
+        r = g_prof[(size_t)i];
+    }
     float t = 0.f;
-    if (hipEventSynchronize(g_prof[i].b) != hipSuccess || hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b) != hipSuccess) t = -1.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = -1.f;
     if (ms) *ms = t;
-    return g_prof[i].name;
+    return r.name;
 }
 
 int hb_init(void) {
@@ -134,6 +172,18 @@ int hb_device_count(void) {
     return g_ndev;
 }
 
+void hb_pool_limit(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_limit = bytes;
+    pool_trim_locked(g_pool_limit);
+}
+size_t hb_pool_cached_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t t = 0;
+    for (auto &b : g_free) t += b.bytes;
+    return t;
+}
+
 void hb_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto &b : g_free) {
@@ -142,29 +192,9 @@ void hb_shutdown(void) {
     g_free.clear();
 }
 
-const char *hb_version(void) { return HB_VERSION_STRING; }
 unsigned hb_last_result_flags(void) { return g_last_flags; }
 void hb_debug_decode_fusion(int on) { g_no_dec_fusion = !on; }
 void hb_debug_plane_mask(unsigned mask) { g_plane_mask = mask; }
-
-const char *hb_strerror(int code) {
-    switch (code) {
-    case HB_OK: return "ok";
-    case HB_ERR_INVALID_DATA: return "blosc: invalid compressed data";            // blosc.go:127
-    case HB_ERR_INVALID_HEADER: return "blosc: invalid header";                   // blosc.go:130
-    case HB_ERR_INVALID_VERSION: return "blosc: unsupported format version";      // blosc.go:133
-    case HB_ERR_INVALID_CODEC: return "blosc: unsupported codec";                 // blosc.go:136
-    case HB_ERR_SIZE_MISMATCH: return "blosc: decompressed size mismatch";        // blosc.go:139
-    case HB_ERR_DATA_TOO_LARGE: return "blosc: data too large";                   // blosc.go:142
-    case HB_ERR_COMPRESSION_FAILED: return "blosc: compression failed";           // blosc.go:145
-    case HB_ERR_DECOMPRESSION_FAILED: return "blosc: decompression failed";       // blosc.go:148
-    case HB_ERR_NO_DEVICE: return "hipblosc: no HIP device";
-    case HB_ERR_HIP: return "hipblosc: HIP runtime error";
-    case HB_ERR_BAD_ARG: return "hipblosc: bad argument";
-    case HB_ERR_SHORT_BUFFER: return "hipblosc: destination or workspace too small";
-    default: return "hipblosc: unknown error";
-    }
-}
 
 void *hb_host_alloc(size_t bytes) {
     std::call_once(g_once, do_init);
@@ -205,8 +235,6 @@ int hb_filter(int op, void *dst, const void *src, size_t n, int typesize, int de
 // ------------------------------------------------------------------------------------------
 // LZ4 block codec
 // ------------------------------------------------------------------------------------------
-size_t hb_lz4_bound(size_t n) { return n + n / 255 + 16; }           // codec.go:65
-size_t hb_index_bound(size_t n) { return hb_lz4_index_bound(n); }
 size_t hb_lz4_compress_workspace(size_t n) { return hb_lz4_enc_workspace(n); }
 size_t hb_lz4_decompress_workspace(size_t n_out) { return hb_lz4_dec_workspace(n_out); }
 
@@ -280,26 +308,6 @@ int64_t hb_lz4_decompress(const void *src, size_t n, void *dst, size_t cap, int 
 // ------------------------------------------------------------------------------------------
 // frame layer
 // ------------------------------------------------------------------------------------------
-static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-static inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
-
-int hb_parse_header(const void *frame, size_t n, hb_header *h) {      // blosc.go:165-185
-    if (!h || (!frame && n)) return HB_ERR_BAD_ARG;
-    if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;
-    const uint8_t *f = (const uint8_t *)frame;
-    h->version = f[0]; h->codec = f[1]; h->flags = f[2]; h->typesize = f[3];
-    h->nbytes = le32(f + 4); h->blocksize = le32(f + 8); h->cbytes = le32(f + 12);
-    if (h->version != HB_FORMAT_VERSION) return HB_ERR_INVALID_VERSION;
-    return HB_OK;
-}
-
-void hb_header_bytes(const hb_header *h, void *out16) {               // blosc.go:188-198
-    uint8_t *o = (uint8_t *)out16;
-    o[0] = h->version; o[1] = h->codec; o[2] = h->flags; o[3] = h->typesize;
-    put32(o + 4, h->nbytes); put32(o + 8, h->blocksize); put32(o + 12, h->cbytes);
-}
-
-size_t hb_frame_bound(size_t n) { return HB_HEADER_SIZE + hb_lz4_bound(n) + 8 + hb_lz4_index_bound(n); }
 size_t hb_compress_frame_workspace(size_t n) { return hb_lz4_enc_workspace(n) + ((n + 255) & ~(size_t)255) + 256; }
 size_t hb_decompress_frame_workspace(size_t n_out) { return hb_lz4_dec_workspace(n_out) + ((n_out + 255) & ~(size_t)255) + 256; }
 
@@ -475,22 +483,6 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     if (r.status) return r.status;
     if (r.bytes) HB_HIP_TRY(hipMemcpy(dst, d_dst, r.bytes, hipMemcpyDeviceToHost));
     return (int64_t)r.bytes;
-}
-
-int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *n, void *const *dst, const size_t *cap,
-                             int64_t *rc, int codec, int level, int shuffle, int typesize, unsigned opts) {
-    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if (nframes < 0 || (nframes && (!src || !n || !dst || !cap || !rc))) return HB_ERR_BAD_ARG;
-    const int nd = g_ndev;
-    std::vector<std::thread> th;
-    for (int d = 0; d < nd && d < nframes; d++) {
-        th.emplace_back([=]() {           // one host thread per device, frames k = d, d+nd, ...
-            for (int k = d; k < nframes; k += nd)
-                rc[k] = hb_compress_frame(src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts, d);
-        });
-    }
-    for (auto &t : th) t.join();
-    return HB_OK;
 }
 
 }  // extern "C"

@@ -110,9 +110,6 @@ static inline EncLayout enc_layout(size_t n) {
     return L;
 }
 size_t hb_lz4_enc_workspace(size_t n) { return enc_layout(n).total; }
-size_t hb_lz4_index_bound(size_t n) {
-    return HB_IDX_HDR_BYTES + (size_t)HB_IDX_ENTRY * ((n + HB_CHUNK - 1) / HB_CHUNK + 1);
-}
 
 // ----------------------------------------------------------------------------------------------
 // k_match

@@ -7,15 +7,21 @@
 // independent engines), which is what the one-call API of hb_api.hip cannot do.
 #include "hb_common.h"
 #include "hb_lz4.h"
+#include "hb_ticket_ring.h"
 
 #include <vector>
 #include <utility>
 #include <new>
+#include <thread>
+#include <algorithm>
 
 extern "C" {
 size_t hb_frame_bound(size_t n);
 size_t hb_compress_frame_workspace(size_t n);
 size_t hb_decompress_frame_workspace(size_t n_out);
+int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int codec, int level, int shuffle, int typesize,
+                          unsigned opts, int device);
+int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, int typesize_override, int device);
 int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap, int codec, int level, int shuffle,
                           int typesize, unsigned opts, void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
 }
@@ -40,8 +46,7 @@ struct hb_queue {
     size_t max_n = 0, in_bytes = 0, out_bytes = 0, work_bytes = 0;
     std::vector<Slot> slots;
     int64_t next_ticket = 0;
-    // results of tickets whose slot was re-used before they were waited for: {ticket, rc}, the newest 4 * depth of them
-    std::vector<std::pair<int64_t, int64_t>> kept;
+    hb_ticket_ring kept;                 // results of tickets whose slot was re-used before they were waited for
 };
 
 namespace {
@@ -77,8 +82,7 @@ Slot *take_slot(hb_queue *q, int64_t *ticket) {
     Slot &s = q->slots[(size_t)(*ticket % (int64_t)q->slots.size())];
     finish(q, s);                        // all slots in flight: the oldest one is completed first ...
     if (s.state == SLOT_DONE && s.ticket >= 0) {   // ... and its result is kept for its hb_queue_wait (the data is already in its dst)
-        if (q->kept.size() >= 4 * q->slots.size()) q->kept.erase(q->kept.begin());
-        q->kept.push_back({s.ticket, s.rc});
+        q->kept.put(s.ticket, s.rc);
     }
     return &s;
 }
@@ -102,6 +106,7 @@ hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes) {
     q->work_bytes = hb_compress_frame_workspace(max_nbytes);
     if (hb_decompress_frame_workspace(max_nbytes) > q->work_bytes) q->work_bytes = hb_decompress_frame_workspace(max_nbytes);
     q->slots.resize((size_t)depth);
+    q->kept = hb_ticket_ring(4 * (size_t)depth);
     bool ok = true;
     for (auto &s : q->slots) {
         ok = ok && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
@@ -173,14 +178,95 @@ int64_t hb_queue_wait(hb_queue *q, int64_t ticket) {
     if (!q || ticket < 0 || ticket >= q->next_ticket) return HB_ERR_BAD_ARG;
     Slot &s = q->slots[(size_t)(ticket % (int64_t)q->slots.size())];
     if (s.ticket != ticket) {                                                 // slot re-used since: the result may have been kept
-        for (size_t i = 0; i < q->kept.size(); i++)
-            if (q->kept[i].first == ticket) { const int64_t rc = q->kept[i].second; q->kept.erase(q->kept.begin() + (long)i); return rc; }
-        return HB_ERR_BAD_ARG;                                                // already waited for, or too old
+        int64_t rc;
+        return q->kept.take(ticket, &rc) ? rc : (int64_t)HB_ERR_BAD_ARG;      // else: already waited for, or too old
     }
     if (s.state == SLOT_FREE) return HB_ERR_BAD_ARG;                          // already waited for
     finish(q, s);
     s.state = SLOT_FREE;
     return s.rc;
+}
+
+
+}  // extern "C"
+
+// ---- batches of independent frames over all devices: frame k -> device k mod hb_device_count() ----
+// One host thread per device, each with its own hb_queue (3 frames in flight: the upload of frame k+1 overlaps the kernels
+// of frame k and the download of frame k-1).  Frames the queue does not carry (host codecs, malformed headers) go through
+// the one-call entry points, which also produce the reference's error for them.  No device talks to another one.
+namespace {
+constexpr int MULTI_DEPTH = 3;
+
+template <class Submit, class OneCall>
+void run_device(int dev, int nd, int nframes, size_t max_n, int64_t *rc, Submit submit, OneCall one_call) {
+    hb_queue *q = max_n ? hb_queue_create(dev, MULTI_DEPTH, max_n) : nullptr;
+    std::vector<std::pair<int, int64_t>> inflight;        // {frame, ticket}
+    auto retire = [&](size_t keep) {
+        while (inflight.size() > keep) {
+            rc[inflight.front().first] = hb_queue_wait(q, inflight.front().second);
+            inflight.erase(inflight.begin());
+        }
+    };
+    for (int k = dev; k < nframes; k += nd) {
+        int64_t t = q ? submit(q, k) : (int64_t)HB_ERR_BAD_ARG;
+        if (t >= 0) { inflight.push_back({k, t}); retire(MULTI_DEPTH - 1); }
+        else rc[k] = one_call(k, dev);                     // not a queue frame: one call (also yields the right error code)
+    }
+    if (q) { retire(0); hb_queue_destroy(q); }
+}
+}  // namespace
+
+extern "C" {
+
+int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *n, void *const *dst, const size_t *cap,
+                             int64_t *rc, int codec, int level, int shuffle, int typesize, unsigned opts) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (nframes < 0 || (nframes && (!src || !n || !dst || !cap || !rc))) return HB_ERR_BAD_ARG;
+    const int nd = hb_device_count();
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd && d < nframes; d++) {
+        th.emplace_back([=]() {
+            size_t max_n = 0;
+            if (codec == HB_LZ4)
+                for (int k = d; k < nframes; k += nd)
+                    if (n[k] <= 0xFFFFFFFFull - HB_HEADER_SIZE - n[k] / 255 - 64) max_n = std::max(max_n, n[k]);
+            run_device(d, nd, nframes, max_n, rc,
+                       [&](hb_queue *q, int k) -> int64_t {
+                           if (codec != HB_LZ4 || !src[k] || !dst[k] || n[k] == 0) return HB_ERR_BAD_ARG;
+                           return hb_queue_compress(q, src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts);
+                       },
+                       [&](int k, int dev) { return hb_compress_frame(src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts, dev); });
+        });
+    }
+    for (auto &t : th) t.join();
+    return HB_OK;
+}
+
+int hb_decompress_frames_multi(int nframes, const void *const *frame, const size_t *n, void *const *dst, const size_t *cap,
+                               int64_t *rc, int typesize_override) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (nframes < 0 || (nframes && (!frame || !n || !dst || !cap || !rc))) return HB_ERR_BAD_ARG;
+    const int nd = hb_device_count();
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd && d < nframes; d++) {
+        th.emplace_back([=]() {
+            size_t max_n = 0;                              // largest decoded size among this device's well-formed LZ4 frames
+            for (int k = d; k < nframes; k += nd) {
+                hb_header h;
+                if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (h.codec == HB_LZ4 || h.codec == HB_LZ4HC || (h.flags & HB_FLAG_MEMCPY)))
+                    max_n = std::max(max_n, std::max<size_t>(h.nbytes, 1));
+            }
+            if (max_n > 0xFFFFFFFFull - HB_HEADER_SIZE - max_n / 255 - 64) max_n = 0;
+            run_device(d, nd, nframes, max_n, rc,
+                       [&](hb_queue *q, int k) -> int64_t {
+                           if (!frame[k] || (!dst[k] && cap[k])) return HB_ERR_BAD_ARG;
+                           return hb_queue_decompress(q, frame[k], n[k], dst[k], cap[k], typesize_override);
+                       },
+                       [&](int k, int dev) { return hb_decompress_frame(frame[k], n[k], dst[k], cap[k], typesize_override, dev); });
+        });
+    }
+    for (auto &t : th) t.join();
+    return HB_OK;
 }
 
 }  // extern "C"

@@ -234,6 +234,45 @@ func CompressFramesHIP(frames [][]byte, opts Options, withIndex bool) ([][]byte,
 	return out, errs
 }
 
+// DecompressFrames is the inverse of CompressFrames: independent frames, frame k on device k mod hb_device_count(),
+// one Decompress (blosc.go:291-303) per frame; errs[k] carries the reference's sentinel for frame k.
+func DecompressFrames(frames [][]byte) (out [][]byte, errs []error) {
+	n := len(frames)
+	out = make([][]byte, n)
+	errs = make([]error, n)
+	if n == 0 {
+		return out, errs
+	}
+	srcs := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	dsts := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	defer C.free(unsafe.Pointer(&srcs[0]))
+	defer C.free(unsafe.Pointer(&dsts[0]))
+	lens := make([]C.size_t, n)
+	caps := make([]C.size_t, n)
+	rcs := make([]C.int64_t, n)
+	for k, f := range frames {
+		lens[k] = C.size_t(len(f))
+		caps[k] = 1
+		if h, err := ParseHeader(f); err == nil {
+			caps[k] = C.size_t(h.NBytesOrig) + 1
+		}
+		srcs[k] = C.hb_host_alloc(lens[k] + 1)
+		dsts[k] = C.hb_host_alloc(caps[k])
+		copy(unsafe.Slice((*byte)(srcs[k]), len(f)), f)
+	}
+	C.hb_decompress_frames_multi(C.int(n), &srcs[0], &lens[0], &dsts[0], &caps[0], &rcs[0], 0)
+	for k := range frames {
+		if rcs[k] < 0 {
+			errs[k] = hbError(rcs[k])
+		} else {
+			out[k] = append([]byte(nil), unsafe.Slice((*byte)(dsts[k]), int(rcs[k]))...)
+		}
+		C.hb_host_free(srcs[k])
+		C.hb_host_free(dsts[k])
+	}
+	return out, errs
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pipelined frames (hb_queue_*): `depth` frames in flight on one device, uploads / kernels / downloads
 // overlapped — for callers that stream many frames (chunked arrays, inputs >= 4 GiB cut into frames).

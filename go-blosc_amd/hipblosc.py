@@ -81,12 +81,12 @@ _BY_CODE = {c.code: c for c in (ErrInvalidData, ErrInvalidHeader, ErrInvalidVers
                                 ErrSizeMismatch, ErrDataTooLarge, ErrCompressionFailed, ErrDecompressionFailed)}
 
 EXPORTS = [
-    "hb_init", "hb_device_count", "hb_shutdown", "hb_strerror", "hb_version", "hb_host_alloc", "hb_host_free",
+    "hb_init", "hb_device_count", "hb_shutdown", "hb_pool_limit", "hb_pool_cached_bytes", "hb_strerror", "hb_version", "hb_host_alloc", "hb_host_free",
     "hb_filter", "hb_filter_dev", "hb_lz4_bound", "hb_lz4_compress", "hb_lz4_decompress",
     "hb_lz4_compress_workspace", "hb_lz4_decompress_workspace", "hb_lz4_compress_dev", "hb_lz4_decompress_dev",
     "hb_index_bound", "hb_parse_header", "hb_header_bytes", "hb_frame_bound", "hb_compress_frame",
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace",
-    "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi",
+    "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
     "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_queue_create", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
@@ -117,6 +117,7 @@ def lib():
         vp, sz, i32, i64, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int64, ctypes.c_uint
         sig = {
             "hb_init": (i32, []), "hb_device_count": (i32, []), "hb_shutdown": (None, []),
+            "hb_pool_limit": (None, [sz]), "hb_pool_cached_bytes": (sz, []),
             "hb_strerror": (ctypes.c_char_p, [i32]), "hb_version": (ctypes.c_char_p, []),
             "hb_host_alloc": (vp, [sz]), "hb_host_free": (None, [vp]),
             "hb_filter": (i32, [i32, vp, vp, sz, i32, i32]),
@@ -136,6 +137,7 @@ def lib():
             "hb_compress_frame_dev": (i32, [vp, sz, vp, sz, i32, i32, i32, i32, u32, vp, sz, vp, vp]),
             "hb_decompress_frame_dev": (i32, [vp, sz, vp, sz, i32, vp, sz, vp, vp]),
             "hb_compress_frames_multi": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, u32]),
+            "hb_decompress_frames_multi": (i32, [i32, vp, vp, vp, vp, vp, i32]),
             "hb_last_result_flags": (u32, []),
             "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
             "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),

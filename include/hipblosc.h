@@ -87,6 +87,9 @@ typedef struct hb_result {
 int         hb_init(void);                 /* idempotent; HB_OK or HB_ERR_NO_DEVICE.  Replaces package init, shuffle.go:3-5 */
 int         hb_device_count(void);         /* 0 when no device */
 void        hb_shutdown(void);             /* frees cached workspaces */
+void        hb_pool_limit(size_t bytes);   /* idle device scratch the host-pointer entry points may keep cached (default 12 GiB, or
+                                              HIPBLOSC_POOL_MAX_MB); what exceeds it is freed at once, largest buffer first */
+size_t      hb_pool_cached_bytes(void);    /* idle scratch currently cached (diagnostics) */
 const char *hb_strerror(int code);
 const char *hb_version(void);
 unsigned    hb_last_result_flags(void);    /* hb_result.flags of the last host-pointer frame decode on this thread
@@ -164,10 +167,16 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
                             int typesize_override,
                             void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
 
-/* batch of independent frames, frame k -> device k mod hb_device_count(); per-frame results in rc[] */
+/* batches of independent frames, frame k -> device k mod hb_device_count(): what a caller with an
+ * 8 GiB array does (8 frames of <= 4 GiB - 1, blosc.go:159-161: the sizes are uint32), one Compress / Decompress call
+ * (blosc.go:257-303) per frame.  One host thread per device, each with its own hb_queue of 3 frames in flight; no
+ * device-to-device traffic.  Per-frame results in rc[] (what hb_compress_frame / hb_decompress_frame would return);
+ * the call itself returns HB_OK unless its arguments are unusable. */
 int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *n,
                              void *const *dst, const size_t *cap, int64_t *rc,
                              int codec, int level, int shuffle, int typesize, unsigned opts);
+int hb_decompress_frames_multi(int nframes, const void *const *frame, const size_t *n,
+                               void *const *dst, const size_t *cap, int64_t *rc, int typesize_override);
 
 /* ---- pipelined host API: frames in flight on their own streams ----
  * The one-call entry points above move H2D -> kernels -> D2H back to back, so a caller sees n / (t_h2d + t_k + t_d2h).

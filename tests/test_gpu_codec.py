@@ -404,11 +404,14 @@ def test_frame_queue_matches_one_call_api(hb, O):
             nb = q.wait(tickets[j])
             sh, ts = modes[j % 4]
             assert bytes(pin_out[j].view[:nb]) == hb.Compress(xs[j], hb.LZ4, 5, sh, ts, opts=hb.OPT_INDEX_TRAILER)
+            # ... and, not only equal to the one-call API: the ORACLE decoder turns the queued frame back into the input
+            assert O.decompress_frame(np.frombuffer(bytes(pin_out[j].view[:nb]), np.uint8)).tobytes() == xs[j]
     frames = {}
     for j in (len(xs) - 1, len(xs) - 2):            # out of order
         nb = q.wait(tickets[j])
         sh, ts = modes[j % 4]
         assert bytes(pin_out[j].view[:nb]) == hb.Compress(xs[j], hb.LZ4, 5, sh, ts, opts=hb.OPT_INDEX_TRAILER)
+        assert O.decompress_frame(np.frombuffer(bytes(pin_out[j].view[:nb]), np.uint8)).tobytes() == xs[j]
     with pytest.raises(hb.HipBloscError):
         q.wait(tickets[0])                          # a ticket is waited for once
     # decode through the queue: frames from pin_out[k] back into pin_in[k]
@@ -422,6 +425,25 @@ def test_frame_queue_matches_one_call_api(hb, O):
         tk.append(q.decompress(pin_out[k].ptr, len(frames[k]), pin_in[k].ptr, mx))
     for k in range(len(xs) - 3, len(xs)):
         assert q.wait(tk[k]) == len(xs[k]) and bytes(pin_in[k].view[:len(xs[k])]) == xs[k]
+    # frames written by the ORACLE (no index trailer: the reference's own output shape) decode through the queue too
+    for k in (0, 1, 3):
+        sh, ts = modes[k % 4]
+        of = O.compress_frame(np.frombuffer(xs[k], np.uint8), shuffle=sh, typesize=ts).tobytes()
+        ctypes.memmove(pin_out[k].ptr, of, len(of))
+        t = q.decompress(pin_out[k].ptr, len(of), pin_in[k].ptr, mx)
+        assert q.wait(t) == len(xs[k]) and bytes(pin_in[k].view[:len(xs[k])]) == xs[k]
+    # a ticket whose slot was re-used before it was waited for keeps its result (hipblosc.h: newest 4 * depth kept)
+    late = []
+    for k in range(5):                              # depth 3: tickets 0 and 1 of this batch lose their slots
+        ctypes.memmove(pin_in[k].ptr, xs[k], len(xs[k]))
+        sh, ts = modes[k % 4]
+        late.append(q.compress(pin_in[k].ptr, len(xs[k]), pin_out[k].ptr, cap, hb.LZ4, 5, sh, ts, 0))
+    for k in (0, 1, 4, 3, 2):
+        sh, ts = modes[k % 4]
+        nb = q.wait(late[k])
+        assert bytes(pin_out[k].view[:nb]) == hb.Compress(xs[k], hb.LZ4, 5, sh, ts, opts=0), k
+    with pytest.raises(hb.HipBloscError):
+        q.wait(late[0])                             # ... once
     # errors keep the reference's identities
     with pytest.raises(hb.ErrInvalidData):
         q.compress(pin_in[0].ptr, 0, pin_out[0].ptr, cap)                       # blosc.go:269-271
@@ -506,3 +528,149 @@ def test_window_that_is_one_run_is_one_match(hb, O):
         assert nseq <= 64 * 3, (head, nseq)
         assert hb.Decompress(fr[0]) == x.tobytes()
         assert np.array_equal(O.decompress_frame(np.frombuffer(fr[0], np.uint8)), x)
+
+
+def _seeds():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_seeds.json")))
+
+
+def test_reference_fuzz_seeds_on_device(hb, O):
+    # The deterministic seed inputs of the reference's own fuzz targets (fuzz_test.go:26-133, :293-363), restated in
+    # tests/golden/reference_seeds.json with outcomes derived by hand from blosc.go.  The device must give, for
+    # Decompress and for DecompressWithSize(ts) with ts in {0,1,2,4,8} (fuzz_test.go:155-158): the stated outcome,
+    # and -- independently of the hand derivation -- exactly what the oracle gives.
+    S = _seeds()
+    by_name = {"ErrInvalidData": hb.ErrInvalidData, "ErrInvalidHeader": hb.ErrInvalidHeader, "ErrInvalidVersion": hb.ErrInvalidVersion,
+               "ErrInvalidCodec": hb.ErrInvalidCodec, "ErrSizeMismatch": hb.ErrSizeMismatch, "ErrDecompressionFailed": hb.ErrDecompressionFailed}
+    by_code = {-1: hb.ErrInvalidData, -2: hb.ErrInvalidHeader, -3: hb.ErrInvalidVersion, -4: hb.ErrInvalidCodec,
+               -5: hb.ErrSizeMismatch, -8: hb.ErrDecompressionFailed}
+
+    def device(data, ts):
+        try:
+            return None, hb.DecompressWithSize(data, ts)
+        except hb.BloscError as e:
+            return type(e), None
+
+    def oracle(data, ts):
+        try:
+            return None, O.decompress_frame(np.frombuffer(data, np.uint8), typesize_override=ts).tobytes()
+        except O.OracleError as e:
+            return by_code[e.code], None
+
+    for s in S["decompress_seeds"]:
+        data = bytes.fromhex(s["data"])
+        for ts in S["decompress_with_size_sweep"]:
+            err, out = device(data, ts)
+            if s["expect"] == "ok":
+                assert err is None and out == bytes.fromhex(s["out"]), (s["name"], ts, err)
+            else:
+                assert err is by_name[s["expect"]], (s["name"], ts, err)
+            assert (err, out) == oracle(data, ts), (s["name"], ts)
+    for s in S["header_seeds"]:
+        data = bytes.fromhex(s["data"])
+        if s["parse"] == "ok":
+            h = hb.ParseHeader(data)
+            f = s["fields"]
+            assert (h.Version, h.VersionLZ, h.Flags, h.TypeSize, h.NBytesOrig, h.BlockSize, h.NBytesComp) == \
+                   (f["Version"], f["VersionLZ"], f["Flags"], f["TypeSize"], f["NBytesOrig"], f["BlockSize"], f["NBytesComp"])
+            assert h.Bytes() == data[:16]                                       # fuzz_test.go:400-421
+            assert hb.GetDecompressedSize(data) == f["NBytesOrig"]              # fuzz_test.go:436-447
+        else:
+            with pytest.raises(by_name[s["parse"]]):
+                hb.ParseHeader(data)
+        err, out = device(data, 0)
+        assert err is (None if s["decompress"] == "ok" else by_name[s["decompress"]]), (s["name"], err)
+        assert (err, out) == oracle(data, 0), s["name"]
+
+
+def test_reference_compress_seeds_on_device(hb, O):
+    # FuzzCompress's seed inputs (fuzz_test.go:167-203): NoShuffle round trips must hold at every level the reference tries
+    # (:256-266), every shuffle x typesize combination must come back too (the default memcpy policy makes even those exact),
+    # odd type sizes are accepted (:269-274); every frame also decodes through the ORACLE decoder.
+    S = _seeds()
+    for s in S["compress_seeds"]:
+        x = bytes.fromhex(s["data"])
+        xa = np.frombuffer(x, np.uint8)
+        for level in S["compress_levels"]:
+            f = hb.Compress(x, hb.LZ4, level, hb.NoShuffle, 1)
+            assert hb.Decompress(f) == x and O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes() == x, (s["name"], level)
+        for shuffle in (hb.NoShuffle, hb.Shuffle1, hb.BitShuffle):
+            for ts in (1, 2, 4, 8):
+                f = hb.Compress(x, hb.LZ4, 5, shuffle, ts)
+                assert hb.Decompress(f) == x, (s["name"], shuffle, ts)
+                assert O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes() == x, (s["name"], shuffle, ts)
+                assert hb.Decompress(O.compress_frame(xa, shuffle=shuffle, typesize=ts).tobytes()) == x, (s["name"], shuffle, ts)
+        for ts in S["compress_odd_typesizes"]:
+            f = hb.Compress(x, hb.LZ4, 5, hb.NoShuffle, ts)
+            assert hb.Decompress(f) == x and f[3] == (max(ts, 1) & 0xFF), (s["name"], ts)
+    with pytest.raises(hb.ErrInvalidData):                                      # fuzz_test.go:205-214
+        hb.Compress(b"", hb.LZ4, 5, hb.NoShuffle, 1)
+
+
+def _forge_index(nunits_entries, payload_bytes, nbytes, chunk_field):
+    """A checksum-correct HBIX header + entries (hb_lz4.h layout) for a literal-only payload."""
+    magic, ver = 0x58494248, 1 | (16 << 16)
+    h = [magic, ver, len(nunits_entries) - 1, chunk_field, payload_bytes, nbytes, 0]
+    h.append(h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5])
+    out = struct.pack("<8I", *h)
+    for e in nunits_entries:
+        out += struct.pack("<4I", *e)
+    return out
+
+
+def test_forged_self_consistent_index_is_not_trusted(hb, O):
+    # ADVICE r1 (high): an index whose units are NOT one HB_CHUNK of output each -- but which is checksum-correct and
+    # self-consistent -- must not steer the fused un-shuffle into decoding one plane twice and another never.
+    # Frame: 64 KiB of data, Shuffle1 ts=4, payload = ONE literal-only LZ4 sequence holding the shuffled bytes.
+    rng = np.random.default_rng(77)
+    n = 65536
+    x = rng.integers(0, 256, n, dtype=np.uint8)
+    sh = O.filter(O.OP_SHUFFLE, x, 4).tobytes()
+    ext = n - 15
+    hdr = bytes([0xF0]) + b"\xff" * (ext // 255) + bytes([ext % 255])
+    payload = hdr + sh
+    cbytes = 16 + len(payload)
+    head = struct.pack("<BBBBIII", 2, hb.LZ4, 0x1, 4, n, n, cbytes)
+    pad = b"\0" * (((cbytes + 7) & ~7) - cbytes)
+    want = O.decompress_frame(np.frombuffer(head + payload, np.uint8)).tobytes()
+    assert want == x.tobytes()
+    for unit in (2048, 4096, 8192):
+        ents = []
+        for d in range(0, n, unit):                       # entry: inside the literal run, rem = n - d, token at payload offset 0
+            ents.append((len(hdr) + d, d, n - d, 0))
+        ents[0] = (0, 0, 0xFFFFFFFF, 0)
+        ents.append((len(payload), n, 0, 0))
+        for chunk_field in (unit, 4096):
+            idx = _forge_index(ents, len(payload), n, chunk_field)
+            got = hb.Decompress(head + payload + pad + idx)
+            assert got == want, (unit, chunk_field)
+            used = hb.lib().hb_last_result_flags() & 1
+            assert used == (1 if (unit == 4096 and chunk_field == 4096) else 0), (unit, chunk_field, used)
+
+
+def test_final_token_with_match_nibble_is_rejected_like_the_reference(hb, O):
+    # ADVICE r1: a block that ends after a literal run whose token announces a match (low nibble != 0) is an error in
+    # UncompressBlock (si == len(src) needs matchNibble == 0; oracle ob_lz4_decompress) -- with or without an index.
+    n = 8192
+    x = np.random.default_rng(5).integers(0, 256, n, dtype=np.uint8).tobytes()
+    ext = n - 15
+    for nib, ok in ((0, True), (3, False)):
+        hdr = bytes([0xF0 | nib]) + b"\xff" * (ext // 255) + bytes([ext % 255])
+        payload = hdr + x
+        cbytes = 16 + len(payload)
+        head = struct.pack("<BBBBIII", 2, hb.LZ4, 0, 1, n, n, cbytes)
+        pad = b"\0" * (((cbytes + 7) & ~7) - cbytes)
+        ents = [(0, 0, 0xFFFFFFFF, 0), (len(hdr) + 4096, 4096, n - 4096, 0), (len(payload), n, 0, 0)]
+        idx = _forge_index(ents, len(payload), n, 4096)
+        for frame in (head + payload, head + payload + pad + idx):
+            try:
+                oracle = O.decompress_frame(np.frombuffer(frame, np.uint8)).tobytes()
+            except O.OracleError as e:
+                oracle = e.code
+            assert (oracle == x) if ok else (oracle == -8)
+            if ok:
+                assert hb.Decompress(frame) == x
+            else:
+                with pytest.raises(hb.ErrDecompressionFailed):
+                    hb.Decompress(frame)

@@ -88,3 +88,37 @@ def test_maximum_frame_size(hb, O):
     assert c == n + 16 and hb.ParseHeader(out[:16].tobytes()).IsMemcpy()
     assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, n, 0, 0) == n
     assert np.array_equal(back, x)
+
+
+def test_config5_float32_shuffle_zstd_1gib(hb, O):
+    # BASELINE.json config 5 at its full per-GPU frame size: 1 GiB float32, Shuffle1 on the device overlapped with host ZSTD
+    # level 3 (one zstd frame per 16 MiB slice).  Checker: libzstd decodes the concatenated frames as DecodeAll would
+    # (codec.go:215-222), then the ORACLE's unshuffle must give the input back; the device decode must too.
+    import ctypes
+    import os
+    zs = None
+    for p in ("/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"):
+        if os.path.exists(p):
+            zs = ctypes.CDLL(p)
+            break
+    if zs is None:
+        pytest.skip("libzstd not in this image")
+    zs.ZSTD_decompress.restype = ctypes.c_size_t
+    zs.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    L = hb.lib()
+    x = O.synth(O.D_F32, GIB // 4, frame=5)
+    cap = L.hb_frame_bound(GIB)
+    out = np.empty(cap, np.uint8)
+    c = L.hb_compress_frame(x.ctypes.data, GIB, out.ctypes.data, cap, hb.ZSTD, 3, hb.Shuffle1, 4, 0, 0)
+    assert c > 16
+    h = hb.ParseHeader(out[:16].tobytes())
+    assert (h.Version, h.VersionLZ, h.Flags, h.TypeSize, h.NBytesOrig, h.BlockSize, h.NBytesComp) == (2, hb.ZSTD, 0x1, 4, GIB, GIB, c)
+    assert 0.30 < c / GIB < 0.45                       # ~0.37
+    filt = np.empty(GIB, np.uint8)
+    r = zs.ZSTD_decompress(filt.ctypes.data, GIB, out.ctypes.data + 16, c - 16)
+    assert r == GIB, "libzstd cannot decode the payload as one concatenation of frames"
+    assert np.array_equal(O.filter(O.OP_UNSHUFFLE, filt, 4), x), "libzstd + oracle unshuffle cannot reproduce the input"
+    del filt
+    back = np.empty(GIB, np.uint8)
+    assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, GIB, 0, 0) == GIB
+    assert np.array_equal(back, x), "device decode of the ZSTD frame differs"

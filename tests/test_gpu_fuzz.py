@@ -87,6 +87,59 @@ def test_frames_multi_entry_point(hb, O):
         f = outs[k].raw[: rcs[k]]
         assert hb.Decompress(f) == xs[k].tobytes()
         assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), xs[k])
+        assert f == hb.Compress(xs[k].tobytes(), hb.LZ4, 5, hb.Shuffle1, 4, opts=hb.OPT_INDEX_TRAILER)
+
+
+def test_frames_multi_decompress_and_mixed_batches(hb, O):
+    # hb_decompress_frames_multi (config 4 is compress AND decompress across GPUs): more frames than queue slots, device
+    # frames with the index, ORACLE-written frames without it, a memcpy frame, and malformed frames whose per-frame rc must be
+    # the reference's error (blosc.go:297-299, :180-182, :385-390, :403-407) while the other frames of the batch still decode.
+    import ctypes
+    L = hb.lib()
+    rng = np.random.default_rng(31)
+    xs = [O.synth(O.D_F32, 30000 + 4096 * k, frame=k).tobytes() for k in range(5)]
+    xs.append(rng.integers(0, 256, 70000, dtype=np.uint8).tobytes())                      # incompressible -> memcpy frame
+    xs.append(O.synth(O.D_I32, 65536, frame=9).tobytes())
+    frames = [hb.Compress(x, hb.LZ4, 5, hb.Shuffle1, 4, opts=hb.OPT_INDEX_TRAILER) for x in xs[:3]]
+    frames += [O.compress_frame(np.frombuffer(x, np.uint8), shuffle=1, typesize=4).tobytes() for x in xs[3:5]]   # reference-shaped
+    frames.append(hb.Compress(xs[5], hb.LZ4, 5, hb.NoShuffle, 1))
+    frames.append(hb.Compress(xs[6], hb.LZ4, 5, hb.BitShuffle, 4, opts=hb.OPT_INDEX_TRAILER))
+    want = [(len(x), x) for x in xs]
+    bad = bytearray(frames[0]); bad[0] = 9
+    frames.append(bytes(bad)); want.append((-3, None))                                    # ErrInvalidVersion
+    frames.append(frames[1][:10]); want.append((-2, None))                                # ErrInvalidHeader
+    bad = bytearray(frames[2]); bad[12:16] = (len(frames[2]) + 100).to_bytes(4, "little")
+    frames.append(bytes(bad)); want.append((-1, None))                                    # ErrInvalidData
+    bad = bytearray(frames[3]); bad[1] = 200
+    frames.append(bytes(bad)); want.append((-4, None))                                    # ErrInvalidCodec
+    n = len(frames)
+    keep = [np.frombuffer(f, np.uint8).copy() for f in frames]
+    outs = [np.zeros(max(len(x), 16), np.uint8) for x in xs] + [np.zeros(1 << 17, np.uint8) for _ in range(n - len(xs))]
+    fp = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
+    fl = (ctypes.c_size_t * n)(*[k.size for k in keep])
+    dp = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    dc = (ctypes.c_size_t * n)(*[o.size for o in outs])
+    rcs = (ctypes.c_int64 * n)(*([-99] * n))
+    assert L.hb_decompress_frames_multi(n, fp, fl, dp, dc, rcs, 0) == 0
+    for k, (rc, x) in enumerate(want):
+        assert rcs[k] == rc, (k, rcs[k], rc)
+        if x is not None:
+            assert outs[k][:rc].tobytes() == x, k
+    # compress side: a batch with an empty frame in the middle (ErrInvalidData, blosc.go:269-271) and mixed sizes
+    srcs = [np.frombuffer(x, np.uint8).copy() for x in xs[:4]]
+    lens = [s.size for s in srcs]; lens[2] = 0
+    caps = [L.hb_frame_bound(s.size) for s in srcs]
+    couts = [np.zeros(c, np.uint8) for c in caps]
+    m = len(srcs)
+    rc2 = (ctypes.c_int64 * m)()
+    assert L.hb_compress_frames_multi(m, (ctypes.c_void_p * m)(*[s.ctypes.data for s in srcs]), (ctypes.c_size_t * m)(*lens),
+                                      (ctypes.c_void_p * m)(*[o.ctypes.data for o in couts]), (ctypes.c_size_t * m)(*caps), rc2,
+                                      hb.LZ4, 5, hb.Shuffle1, 4, 0) == 0
+    for k in range(m):
+        if k == 2:
+            assert rc2[k] == -1
+        else:
+            assert rc2[k] > 16 and O.decompress_frame(couts[k][:rc2[k]]).tobytes() == xs[k], k
 
 
 def test_random_shapes_round_trip_and_decode_with_the_reference_decoder(hb, O):

@@ -32,3 +32,30 @@ def test_host_mirror_gpu(hb):
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "device round trips" in out.stdout
+
+
+def test_host_helpers_under_sanitizers(tmp_path):
+    """The host-only parts of the product (csrc/hb_host.cpp, csrc/hb_ticket_ring.h) under -fsanitize=address,undefined, fed with
+    the reference's fuzz seeds (tests/golden/reference_seeds.json) and byte mutations of them.  CPU build only."""
+    import json
+    import random
+    import struct
+    S = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_seeds.json")))
+    blobs = [bytes.fromhex(s["data"]) for s in S["decompress_seeds"] + S["header_seeds"]]
+    rnd = random.Random(7)
+    for b in list(blobs):
+        if len(b) >= 16:
+            m = bytearray(b)
+            m[rnd.randrange(len(m))] ^= 1 << rnd.randrange(8)
+            blobs.append(bytes(m))
+            blobs.append(b[:rnd.randrange(len(b))])
+    path = tmp_path / "blobs.bin"
+    with open(path, "wb") as f:
+        for b in blobs:
+            f.write(struct.pack("<I", len(b)) + b)
+    exe = str(tmp_path / "host_asan_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "tools", "host_asan_check.cpp")])
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ok under ASan" in out.stdout

@@ -22,18 +22,24 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
-    import oracle as O
+    import time
     frames = bench.frames_of_rank(8, rank, world)
-    host = bench.synth_host("f32", 1 << 16, frame=frames[0])
-    f = O.compress_frame(host, shuffle=1, typesize=4)                     # the oracle stands in for the device here
-    assert np.array_equal(O.decompress_frame(f), host)
-    elapsed = bench.max_over_ranks(0.5 + rank, torch.device("cpu"))
+    host = bench.synth_host("f32", 1 << 16, frame=frames[0])              # (data generation only: the oracle's synth)
+    # bench.py's own timed region (bench.timed_steps: warm-up, barrier + sync, exactly K steps, barrier + sync, MAX over
+    # ranks) with a CPU stand-in for the device step: rank r's step takes 20 ms * (r + 1), so the slowest rank sets the time
+    calls = []
+
+    def step():
+        calls.append(time.perf_counter())
+        time.sleep(0.02 * (rank + 1))
+    elapsed = bench.timed_steps(step, 5, 2, lambda: None, dist.barrier, torch.device("cpu"))
+    assert len(calls) == 7                                                # 2 warm-up + exactly 5 timed steps
     digest = int(np.frombuffer(host.tobytes(), np.uint32).sum() % (1 << 31))
     all_d = [None] * world
-    dist.all_gather_object(all_d, (frames, digest, int(f.size)))
+    dist.all_gather_object(all_d, (frames, digest, elapsed))
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, elapsed, all_d, bench.aggregate_gbps(1 << 16, world, 3, elapsed)))
+    q.put((rank, elapsed, all_d, bench.aggregate_gbps(1 << 16, world, 5, elapsed)))
 
 
 def test_frames_shard_across_ranks_gloo():
@@ -48,8 +54,21 @@ def test_frames_shard_across_ranks_gloo():
         p.join(60)
         assert p.exitcode == 0
     for rank, elapsed, all_d, gbps in res:
-        assert elapsed == pytest.approx(1.5)                               # MAX over ranks of (0.5, 1.5)
-        assert gbps == pytest.approx(world * (1 << 16) * 3 / 1.5 / 1e9)    # whole-job aggregate
+        assert 0.2 <= elapsed < 0.6                                        # 5 steps of the SLOWEST rank (40 ms each), not of rank 0
+        assert elapsed == all_d[0][2] == all_d[1][2]                       # every rank reports the same MAX
+        assert gbps == pytest.approx(world * (1 << 16) * 5 / elapsed / 1e9)   # whole-job aggregate: all ranks' frames / that time
     frames0, frames1 = res[0][2][0][0], res[0][2][1][0]
     assert frames0 == [0, 2, 4, 6] and frames1 == [1, 3, 5, 7]             # frame k -> rank k mod G
     assert res[0][2][0][1] != res[0][2][1][1], "ranks must work on different frames"
+
+
+def test_single_rank_uses_the_same_timed_region():
+    # N = 1 (what BENCH_rNN.json is): same function, no process group -> the elapsed time is this rank's own
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    n = []
+    t = bench.timed_steps(lambda: (n.append(1), time.sleep(0.01)), 4, 1, lambda: None, lambda: None, torch.device("cpu"))
+    assert len(n) == 5 and 0.04 <= t < 0.2
+    assert bench.aggregate_gbps(1 << 30, 1, 4, t) == pytest.approx(4 * (1 << 30) / t / 1e9)
+    assert bench.frames_of_rank(8, 0, 1) == list(range(8))
