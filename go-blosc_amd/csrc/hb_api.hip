@@ -317,10 +317,10 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
     if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271
     if (!d_src || !d_frame || !d_work || !d_result) return HB_ERR_BAD_ARG;
     if (typesize <= 0) typesize = 1;                                  // blosc.go:274-276
-    if (level < 1) level = 1;                                         // blosc.go:277-279 (LZ4 ignores level, codec.go:63-66)
-    if (level > 9) level = 9;
-    (void)level;
-    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;                 // only the LZ4 codec is on the device path
+    if (level < 1) level = 1;                                         // blosc.go:277-279
+    if (level > 9) level = 9;                                         // :280-282
+    // device codecs: LZ4 (codec.go:59-84), LZ4HC (:90-128, same block format, deeper search by level), Snappy (:228-244)
+    if (!hb_device_codec(codec)) return HB_ERR_INVALID_CODEC;
     if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
     if (cap < hb_frame_bound(n)) return HB_ERR_SHORT_BUFFER;
     if (work_bytes < hb_compress_frame_workspace(n)) return HB_ERR_SHORT_BUFFER;
@@ -345,7 +345,7 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
     hb_enc_args a{};
     a.src = in; a.n = n; a.dst = (uint8_t *)d_frame; a.cap = cap; a.index = nullptr;
     a.work = enc_work; a.result = d_result;
-    a.frame = 1; a.codec = codec; a.shuffle = shuffle; a.typesize = typesize; a.opts = opts;
+    a.frame = 1; a.codec = codec; a.shuffle = shuffle; a.typesize = typesize; a.opts = opts; a.level = level;
     a.fused_ts = fused ? typesize : 0;
     a.fused_bits = fused_bits ? 4 : 0;
     // what a memcpy frame stores: blosc.go:343-345 (raw input) vs the round-trip-safe filtered bytes
@@ -379,8 +379,9 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;
     if ((size_t)h.cbytes > n) return HB_ERR_INVALID_DATA;             // blosc.go:385-387
     if (h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;        // blosc.go:388-390
-    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;  // :403-407
+    if (!(h.flags & HB_FLAG_MEMCPY) && !hb_device_codec(h.codec)) return HB_ERR_INVALID_CODEC;   // :403-407
     if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
+    const bool snappy = h.codec == HB_SNAPPY && !(h.flags & HB_FLAG_MEMCPY);
     if (work_bytes < hb_decompress_frame_workspace(h.nbytes)) return HB_ERR_SHORT_BUFFER;
     const int ts = typesize_override > 0 ? typesize_override : (int)h.typesize;   // blosc.go:417-419
     int unf = -1;
@@ -392,12 +393,12 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     // bit-unshuffle with typesize 4 works inside 32-byte windows: fused into the indexed decoder when there are only
     // whole windows (the serial fallback still goes through `staged` + a gated un-filter pass, hb_lz4_dec.hip)
     const bool fused_bun = unf == HB_OP_BITUNSHUFFLE && ts == 4 && (h.nbytes % 32u) == 0 && !(h.flags & HB_FLAG_MEMCPY) &&
-                           ((uintptr_t)d_dst & 15u) == 0;
+                           ((uintptr_t)d_dst & 15u) == 0 && !snappy;
     // byte un-shuffle: fused into the indexed decoder (byte-strided stores) when the frame is whole planes of whole chunks
     // (typesize 8: every 128-byte line would be completed by 8 different waves -- measured 0.2 ms per GiB SLOWER than the
     // separate pass, while typesize 2 and 4 win 0.2 ms)
     const bool fused_ush = unf == HB_OP_UNSHUFFLE && ts <= 4 && (h.nbytes % (uint32_t)ts) == 0 &&
-                           ((h.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && !(h.flags & HB_FLAG_MEMCPY) && !g_no_dec_fusion;
+                           ((h.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && !(h.flags & HB_FLAG_MEMCPY) && !g_no_dec_fusion && !snappy;
     uint8_t *target = (unf >= 0 && !fused_bun && !fused_ush) ? staged : (uint8_t *)d_dst;
     const uint8_t *payload = (const uint8_t *)d_frame + HB_HEADER_SIZE;
     const size_t plen = h.cbytes - HB_HEADER_SIZE;
@@ -412,7 +413,7 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     // restart index, if any, sits after cbytes (ignored by the reference decoder, blosc.go:385-393)
     const size_t ioff = ((size_t)h.cbytes + 7) & ~(size_t)7;
     if (!a.memcpy_payload && n > ioff + 32) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }
-    rc = hb_launch_lz4_decode(a, s);
+    rc = snappy ? hb_launch_snappy_decode(a, s) : hb_launch_lz4_decode(a, s);
     if (rc) return rc;
     if (unf >= 0) {
         // length check (blosc.go:429-431) is done on the device; the un-filter runs on nbytes bytes, as the
@@ -429,7 +430,7 @@ int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int 
                           int typesize, unsigned opts, int device) {
     if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271 (before anything else)
     if (!src || !dst) return HB_ERR_BAD_ARG;
-    if (codec != HB_LZ4 && !(codec == HB_ZSTD && hb_zstd_available())) return HB_ERR_INVALID_CODEC;   // blosc.go:322-325
+    if (!hb_device_codec(codec) && !(codec == HB_ZSTD && hb_zstd_available())) return HB_ERR_INVALID_CODEC;   // blosc.go:322-325
     // the header fields are uint32 (blosc.go:159-161); the reference truncates silently (:363-365), this does not
     if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
     int rc = select_device(device);
@@ -466,7 +467,7 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
         g_last_flags = 0;
         return hb_zstd_decompress_frame(frame, h, dst, cap, typesize_override, device);
     }
-    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;
+    if (!(h.flags & HB_FLAG_MEMCPY) && !hb_device_codec(h.codec)) return HB_ERR_INVALID_CODEC;
     rc = select_device(device);
     if (rc) return rc;
     if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;

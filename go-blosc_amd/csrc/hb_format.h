@@ -22,3 +22,11 @@
 #define HB_IDX_ENTRY     16u
 #define HB_IDX_AT_TOKEN  0xFFFFFFFFu
 
+
+// Unit index of a Snappy payload ("HBSX"), same place as HBIX (after cbytes).  A Snappy block is a plain concatenation of
+// elements and this encoder never lets an element straddle two 4 KiB chunks of output, so a unit needs one number only:
+//   header  : 8 x u32 { magic, version|entry_size<<16, nunits, chunk_bytes, payload_bytes, nbytes, uvarint_bytes, check }
+//   entries : (nunits + 1) x u32 payload offset of the first element of unit k (entry nunits = payload_bytes)
+#define HB_SNX_MAGIC     0x58534248u     // "HBSX"
+#define HB_SNX_HDR_BYTES 32u
+#define HB_SNX_ENTRY     4u

@@ -10,6 +10,7 @@ struct hb_enc_args {
     uint8_t *index;                      // frame == 0: optional external index buffer
     uint8_t *work; hb_result *result;
     int frame, codec, shuffle, typesize;
+    int level;                           // Options.Level after clamping (blosc.go:277-282): search depth / skip policy, see enc_policy()
     unsigned opts;
     const uint8_t *memcpy_src;           // what a memcpy frame stores (filtered bytes, or raw with HB_OPT_REFERENCE_MEMCPY);
                                          // NULL with fused_ts: the payload is shuffled in place by a gated filter launch
@@ -44,6 +45,9 @@ size_t hb_lz4_dec_workspace(size_t n_out);
 size_t hb_lz4_index_bound(size_t n);
 int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s);
 int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s);
+// hb_snappy.hip: Snappy block decoder (codec.go:237-244); same argument record, the fused un-filter fields are ignored
+int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s);
+static inline bool hb_device_codec(int codec) { return codec == HB_LZ4 || codec == HB_LZ4HC || codec == HB_SNAPPY; }
 
 // ---- small device helpers shared by encoder and decoder ----
 __device__ __forceinline__ uint32_t lz4_ext_bytes(uint32_t x) { return x < 15u ? 0u : 1u + (x - 15u) / 255u; }

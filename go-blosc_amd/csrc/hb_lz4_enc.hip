@@ -139,13 +139,23 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 // s_q are this wave's scratch; the record goes to `rec`, the summary to *dsc.  with_trailing: also append the
 // un-matched tail of the chunk to the record (fused filter: there is no filtered buffer in HBM for k_stitch to
 // take literals from; a chunk without any match then stores its whole image).
+//
+// WAYS: candidates per hash bucket.  1 = the LZ4 matcher (lz4.CompressBlock's single most-recent candidate, codec.go:63-75).
+//       2 / 4 = the LZ4HC levels (codec.go:96-106 maps level 1-3 / 4-5 / 6-7 / 8-9 to CompressBlockHC Level1 / 5 / 7 / 9, i.e. to
+//       deeper searches): the bucket keeps the last WAYS positions of its hash, every one is verified and extended to 20 bytes,
+//       the longest wins.
+// SNAPPY: emit Snappy elements (codec.go:228-244 -> snappy.Encode) instead of LZ4 sequences; the record is then the chunk's
+//       complete, self-contained element stream (a Snappy block is a plain concatenation of elements: nothing to stitch).
+// accel: bytes by which a step without any hit widens the stride (LZ4-style skip acceleration; Options.Level as a speed knob:
+//       128 for levels 1-3, 64 for 4-6 (the default level 5), 0 for 7-9 and for every LZ4HC level).
+template <int WAYS, bool SNAPPY>
 __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_t sh, const int len,
                                             uint8_t *s_out /* SOUT + 16 */, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */, uint32_t *s_st /* 8 words */,
-                                            ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const bool keep_long, const int lane) {
+                                            ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const bool keep_long, const int accel, const int lane) {
     {
         {
             u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-            for (uint32_t i = lane; i < HSIZE * 2 / 16; i += 64) ((u32x4 *)s_tab)[i] = z;
+            for (uint32_t i = lane; i < HSIZE * WAYS * 2 / 16; i += 64) ((u32x4 *)s_tab)[i] = z;
             if (lane < 2) ((u32x4 *)s_st)[lane] = z;
         }
         wave_sync();
@@ -291,6 +301,87 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             st_state();
         };
 
+        // ---- Snappy emitter (SNAPPY): [literal element][copy elements] per queued sequence; format_description.txt of Snappy:
+        // literal tag = (len-1) << 2 | 0 (len-1 >= 60: 60 / 61 = one / two extra length bytes), copy with 1-byte offset
+        // tag = (off >> 8) << 5 | (len-4) << 2 | 1 (len 4..11, off < 2048), copy with 2-byte offset tag = (len-1) << 2 | 2 (len 1..64).
+        // Long matches are cut as the reference encoder's emitCopy cuts them: 64-byte copies while >= 68 remain, then 60 if > 64.
+        auto sn_lit_header = [&](uint32_t q, uint32_t lit) __attribute__((always_inline)) -> uint32_t {     // lit >= 1
+            const uint32_t x = lit - 1u;
+            if (x < 60u) { s_out[q] = (uint8_t)(x << 2); return 1u; }
+            if (x < 256u) { s_out[q] = (uint8_t)(60u << 2); s_out[q + 1] = (uint8_t)x; return 2u; }
+            s_out[q] = (uint8_t)(61u << 2); s_out[q + 1] = (uint8_t)x; s_out[q + 2] = (uint8_t)(x >> 8); return 3u;
+        };
+        auto sn_copies = [&](uint32_t q, uint32_t ml, uint32_t off) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t q0 = q;
+            while (ml >= 68u) { s_out[q] = (uint8_t)((63u << 2) | 2u); s_out[q + 1] = (uint8_t)off; s_out[q + 2] = (uint8_t)(off >> 8); q += 3u; ml -= 64u; }
+            if (ml > 64u) { s_out[q] = (uint8_t)((59u << 2) | 2u); s_out[q + 1] = (uint8_t)off; s_out[q + 2] = (uint8_t)(off >> 8); q += 3u; ml -= 60u; }
+            if (ml >= 12u || off >= 2048u) { s_out[q] = (uint8_t)(((ml - 1u) << 2) | 2u); s_out[q + 1] = (uint8_t)off; s_out[q + 2] = (uint8_t)(off >> 8); q += 3u; }
+            else { s_out[q] = (uint8_t)(((off >> 8) << 5) | ((ml - 4u) << 2) | 1u); s_out[q + 1] = (uint8_t)off; q += 2u; }
+            return q - q0;
+        };
+        auto flush_sn = [&]() __attribute__((always_inline)) {
+            ld_state();
+            const int take = nq < 64 ? nq : 64;
+            const uint2 e = s_q[lane];
+            const uint32_t q_mp = e.x & 0xFFFFu, q_ml = e.x >> 16, q_off = e.y;
+            const uint32_t end = q_mp + q_ml;
+            const uint32_t prev = wave_shr1(end, batch_anchor);
+            const uint32_t lit = q_mp - prev;
+            const uint32_t lh = lit == 0u ? 0u : (lit <= 60u ? 1u : (lit <= 256u ? 2u : 3u));
+            const uint32_t n64 = q_ml >= 68u ? (q_ml - 68u) / 64u + 1u : 0u;
+            const uint32_t rem = q_ml - 64u * n64;                 // 4..67
+            const uint32_t r60 = rem > 64u ? 1u : 0u;
+            const uint32_t fin = rem - 60u * r60;                  // 4..64
+            const uint32_t csz = 3u * (n64 + r60) + ((fin >= 12u || q_off >= 2048u) ? 3u : 2u);
+            const uint32_t size = lane < take ? lh + lit + csz : 0u;
+            const uint32_t incl = wave_incl_scan_dpp(size);
+            int cnt = __builtin_popcountll(hb_ballot(lane < take && incl <= SOUT - opend));
+            if (cnt == 0) {                                        // a literal run longer than the staging buffer: header, pieces, copies
+                cnt = 1;
+                uint32_t hl = 0;
+                if (lane == 0) hl = sn_lit_header(opend, lit);
+                opend += (uint32_t)__builtin_amdgcn_readlane(hl, 0);
+                wave_sync();
+                stream_literals(__builtin_amdgcn_readlane(prev, 0), __builtin_amdgcn_readlane(lit, 0));
+                uint32_t cl = 0;
+                if (lane == 0) cl = sn_copies(opend, q_ml, q_off);
+                opend += (uint32_t)__builtin_amdgcn_readlane(cl, 0);
+            } else {
+                const bool act = lane < cnt;
+                uint32_t q = opend + incl - size;
+                uint32_t litdst = 0;
+                if (act) {
+                    if (lit) q += sn_lit_header(q, lit);
+                    litdst = q;
+                    if (lit <= LITCAP) lds_copy_exact(s_out + q, data + prev, lit);
+                    q += lit;
+                    sn_copies(q, q_ml, q_off);
+                }
+                unsigned long long lm = hb_ballot(act && lit > LITCAP);
+                while (lm) {                                       // long literal runs: the whole wave copies
+                    const int l = __builtin_ctzll(lm);
+                    const uint32_t sp = __builtin_amdgcn_readlane(prev, l), dq = __builtin_amdgcn_readlane(litdst, l);
+                    const uint32_t ln = __builtin_amdgcn_readlane(lit, l);
+                    for (uint32_t k = lane * 4u; k < ln; k += 256u) {
+                        if (k + 4u <= ln) ((hb_u32u *)(s_out + dq + k))->v = ((const hb_u32u *)(data + sp + k))->v;
+                        else for (uint32_t r = k; r < ln; r++) s_out[dq + r] = data[sp + r];
+                    }
+                    lm &= lm - 1;
+                }
+                opend += (uint32_t)__builtin_amdgcn_readlane(incl, cnt - 1);
+            }
+            batch_anchor = __builtin_amdgcn_readlane(end, cnt - 1);
+            nseq += cnt;
+            const uint32_t i0 = (uint32_t)(lane + cnt), i1 = i0 + 64u;
+            const uint2 r0 = s_q[i0 < QCAP ? i0 : 0], r1 = s_q[i1 < QCAP ? i1 : 0];
+            drain(false);
+            nq -= cnt;
+            if (lane < nq) s_q[lane] = r0;
+            if (lane + 64 < nq) s_q[lane + 64] = r1;
+            st_state();
+        };
+        auto flush_any = [&]() __attribute__((always_inline)) { if constexpr (SNAPPY) flush_sn(); else flush(); };
+
         while (pos <= mstart_max) {
             const int p = pos + lane;
             // ---- 12 bytes at my position: 4 aligned dwords + v_alignbyte (one LDS round trip) ----
@@ -314,20 +405,73 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const unsigned long long m_rle = hb_ballot(valid) & hb_ballot(v == b4) & m_eqprev & m_first;
             const bool rle = valid && (pos > 0 || lane > 0) && v == b4 && before == vb;
             const uint32_t h = (v * 2654435761u) >> (32 - HLOG);
-            uint32_t cand = s_tab[h];
-            if (valid && !rle) s_tab[h] = (uint16_t)p;
-            // ---- 12 bytes at the candidate (second round trip) ----
-            const uint32_t ac = sh + cand;
-            const uint32_t *wc = (const uint32_t *)s_data + (ac >> 2);
-            const uint32_t c0 = wc[0], c1 = wc[1], c2 = wc[2], c3 = wc[3];
-            const uint32_t cv = __builtin_amdgcn_alignbyte(c1, c0, ac & 3u);
-            const uint32_t cv4 = __builtin_amdgcn_alignbyte(c2, c1, ac & 3u);
-            const uint32_t cv8 = __builtin_amdgcn_alignbyte(c3, c2, ac & 3u);
-            const unsigned long long m_hit = hb_ballot(valid) & hb_ballot((int)cand < p) & hb_ballot(cv == v);
-            const bool hit = valid && (int)cand < p && cv == v;
-            // the offset-1 candidate of a run needs no second read: its match is the rest of the run
-            const uint32_t xa = hit ? (cv4 ^ v4) : (b4 ^ v4), xb = hit ? (cv8 ^ v8) : (b4 ^ v8);
-            cand = hit ? cand : (uint32_t)p - 1u;
+            uint32_t cand, xa, xb, ac = 0, hc_fbit = 0;
+            const uint32_t *wc = nullptr;
+            uint32_t c3 = 0;
+            bool hit;
+            unsigned long long m_hit;
+            if constexpr (WAYS == 1) {
+                cand = s_tab[h];
+                if (valid && !rle) s_tab[h] = (uint16_t)p;
+                // ---- 12 bytes at the candidate (second round trip) ----
+                ac = sh + cand;
+                wc = (const uint32_t *)s_data + (ac >> 2);
+                const uint32_t c0 = wc[0], c1 = wc[1], c2 = wc[2];
+                c3 = wc[3];
+                const uint32_t cv = __builtin_amdgcn_alignbyte(c1, c0, ac & 3u);
+                const uint32_t cv4 = __builtin_amdgcn_alignbyte(c2, c1, ac & 3u);
+                const uint32_t cv8 = __builtin_amdgcn_alignbyte(c3, c2, ac & 3u);
+                m_hit = hb_ballot(valid) & hb_ballot((int)cand < p) & hb_ballot(cv == v);
+                hit = valid && (int)cand < p && cv == v;
+                // the offset-1 candidate of a run needs no second read: its match is the rest of the run
+                xa = hit ? (cv4 ^ v4) : (b4 ^ v4); xb = hit ? (cv8 ^ v8) : (b4 ^ v8);
+                cand = hit ? cand : (uint32_t)p - 1u;
+            } else {
+                // ---- LZ4HC: the bucket holds the last WAYS positions of this hash; the new one goes in front ----
+                uint32_t cw[WAYS];
+                if constexpr (WAYS == 2) {
+                    uint32_t *b = (uint32_t *)s_tab + h;
+                    const uint32_t w = *b;
+                    cw[0] = w & 0xFFFFu; cw[1] = w >> 16;
+                    if (valid && !rle) *b = (uint32_t)p | (cw[0] << 16);
+                } else {
+                    u32x2 *b = (u32x2 *)s_tab + h;
+                    const u32x2 w = *b;
+                    cw[0] = w.x & 0xFFFFu; cw[1] = w.x >> 16; cw[2] = w.y & 0xFFFFu; cw[3] = w.y >> 16;
+                    if (valid && !rle) { u32x2 nw; nw.x = (uint32_t)p | (cw[0] << 16); nw.y = cw[1] | (cw[2] << 16); *b = nw; }
+                }
+                // 20 bytes at my position and at every candidate; the longest verified candidate wins (nearest first on ties)
+                const uint32_t p4 = wp[4], p5 = wp[5];
+                const uint32_t v12 = __builtin_amdgcn_alignbyte(p4, p3, ap & 3u), v16 = __builtin_amdgcn_alignbyte(p5, p4, ap & 3u);
+                hit = false; cand = (uint32_t)p - 1u;
+#pragma unroll
+                for (int k = 0; k < WAYS; k++) {
+                    const uint32_t a2 = sh + cw[k];
+                    const uint32_t *w2 = (const uint32_t *)s_data + (a2 >> 2);
+                    const uint32_t d0 = w2[0], d1 = w2[1], d2 = w2[2], d3 = w2[3], d4 = w2[4], d5 = w2[5];
+                    const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, a2 & 3u), e4 = __builtin_amdgcn_alignbyte(d2, d1, a2 & 3u);
+                    const uint32_t e8 = __builtin_amdgcn_alignbyte(d3, d2, a2 & 3u), e12 = __builtin_amdgcn_alignbyte(d4, d3, a2 & 3u);
+                    const uint32_t e16 = __builtin_amdgcn_alignbyte(d5, d4, a2 & 3u);
+                    uint32_t fa, fb, fc, fd;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(e4 ^ v4));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(e8 ^ v8));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fc) : "v"(e12 ^ v12));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fd) : "v"(e16 ^ v16));
+                    const uint32_t f = min(fa, min(fb, min(fc, min(fd, 32u) + 32u) + 32u) + 32u);
+                    const bool ok = valid && (int)cw[k] < p && e0 == v;
+                    if (ok && (!hit || f > hc_fbit)) { hit = true; hc_fbit = f; cand = cw[k]; }
+                }
+                m_hit = hb_ballot(hit);
+                if (!hit) {                                     // the offset-1 candidate of a run: its match is the rest of the run
+                    uint32_t fa, fb, fc, fd;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(b4 ^ v4));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(b4 ^ v8));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fc) : "v"(b4 ^ v12));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fd) : "v"(b4 ^ v16));
+                    hc_fbit = min(fa, min(fb, min(fc, min(fd, 32u) + 32u) + 32u) + 32u);
+                }
+                xa = 0; xb = 0;
+            }
             unsigned long long mask = m_hit | m_rle;
             if (mask) {
                 // An entry whose candidate still matches 12 bytes or more is put BACK: repeated content then keeps pointing
@@ -335,20 +479,25 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 // that each copy the one before (bitshuffled integers: 27 dependency rounds per 64 tokens otherwise, 5
                 // with this); the ratio does not move.  Not in the fused byte-shuffle kernels: their long matches are runs
                 // (offset 1), and the extra LDS write costs their step loop 3 %.
-                if (keep_long && hit && (xa | xb) == 0u) s_tab[h] = (uint16_t)cand;
-                // every lane extends its own match to at most 20 bytes, branch-free (two more dwords on each side, read
-                // on this path only): v_ffbl_b32 gives -1 for 0, so the first differing bit of the 16 bytes is
-                // min(ffbl(xa), 32 + min(ffbl(xb), 32 + min(ffbl(xc), 32 + min(ffbl(xd), 32))))
-                const uint32_t p4 = wp[4], p5 = wp[5], c4 = wc[4], c5 = wc[5];
-                const uint32_t v12 = __builtin_amdgcn_alignbyte(p4, p3, ap & 3u), v16 = __builtin_amdgcn_alignbyte(p5, p4, ap & 3u);
-                const uint32_t cv12 = __builtin_amdgcn_alignbyte(c4, c3, ac & 3u), cv16 = __builtin_amdgcn_alignbyte(c5, c4, ac & 3u);
-                const uint32_t xc = hit ? (cv12 ^ v12) : (b4 ^ v12), xd = hit ? (cv16 ^ v16) : (b4 ^ v16);
-                uint32_t fa, fb, fc, fd;
-                asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(xa));
-                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(xb));
-                asm("v_ffbl_b32 %0, %1" : "=v"(fc) : "v"(xc));
-                asm("v_ffbl_b32 %0, %1" : "=v"(fd) : "v"(xd));
-                const uint32_t fbit = min(fa, min(fb, min(fc, min(fd, 32u) + 32u) + 32u) + 32u);
+                uint32_t fbit;
+                if constexpr (WAYS == 1) {
+                    if (keep_long && hit && (xa | xb) == 0u) s_tab[h] = (uint16_t)cand;
+                    // every lane extends its own match to at most 20 bytes, branch-free (two more dwords on each side, read
+                    // on this path only): v_ffbl_b32 gives -1 for 0, so the first differing bit of the 16 bytes is
+                    // min(ffbl(xa), 32 + min(ffbl(xb), 32 + min(ffbl(xc), 32 + min(ffbl(xd), 32))))
+                    const uint32_t p4 = wp[4], p5 = wp[5], c4 = wc[4], c5 = wc[5];
+                    const uint32_t v12 = __builtin_amdgcn_alignbyte(p4, p3, ap & 3u), v16 = __builtin_amdgcn_alignbyte(p5, p4, ap & 3u);
+                    const uint32_t cv12 = __builtin_amdgcn_alignbyte(c4, c3, ac & 3u), cv16 = __builtin_amdgcn_alignbyte(c5, c4, ac & 3u);
+                    const uint32_t xc = hit ? (cv12 ^ v12) : (b4 ^ v12), xd = hit ? (cv16 ^ v16) : (b4 ^ v16);
+                    uint32_t fa, fb, fc, fd;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(xa));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(xb));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fc) : "v"(xc));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fd) : "v"(xd));
+                    fbit = min(fa, min(fb, min(fc, min(fd, 32u) + 32u) + 32u) + 32u);
+                } else {
+                    fbit = hc_fbit;
+                }
                 uint32_t ml = 4u + (fbit >> 3);
                 const uint32_t maxl = (uint32_t)(mend_max - p);
                 unsigned long long lmask = mask & hb_ballot(fbit == 128u) & hb_ballot(ml < maxl);
@@ -431,16 +580,36 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 }
                 nq += __builtin_popcountll(sel);
                 anchor = last_end;
-                while (nq >= 64) flush();
+                while (nq >= 64) flush_any();
                 miss = 0;
             } else {
                 miss++;
             }
-            const int nxt = pos + 64 + (miss << 6);             // every step without a hit widens the stride by 64 bytes
+            const int nxt = pos + 64 + miss * accel;            // every step without a hit widens the stride by `accel` bytes
             pos = anchor > nxt ? anchor : nxt;
         }
-        while (nq > 0) flush();
+        while (nq > 0) flush_any();
         ld_state();
+        if constexpr (SNAPPY) {
+            // the rest of the chunk is one literal element; the record is the chunk's complete element stream
+            const uint32_t tl = (uint32_t)(len - anchor);
+            if (tl) {
+                uint32_t hl = 0;
+                if (lane == 0) hl = sn_lit_header(opend, tl);
+                opend += (uint32_t)__builtin_amdgcn_readlane(hl, 0);
+                wave_sync();
+                stream_literals((uint32_t)anchor, tl);
+            }
+            const uint32_t total = rec_done + opend;
+            drain(true);
+            if (lane == 0) {
+                ChunkDesc d;
+                d.lead = 0u; d.enc_len = total; d.last_end = (uint32_t)len; d.mcode0 = 0u;
+                *dsc = d;
+            }
+            wave_sync();
+            return;
+        }
         const uint32_t enc = rec_done + opend;             // record bytes without the trailing literals
         if (with_trailing) {
             if (nseq == 0 && sh == 0) {            // no match at all: the record is the image itself
@@ -465,12 +634,13 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 // bits4 != 0: src is the UN-filtered input and go-blosc's bitshuffle for typesize 4 (an in-place transform of every
 // 32-byte window, shuffle.go:184-200) is applied to the chunk image in LDS -- filter fused, no filtered buffer in
 // HBM; the caller guarantees n % 32 == 0 and a 16-byte aligned src.
+template <int WAYS, bool SNAPPY>
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
-                                              uint32_t nchunks, int bits4, int keep_long) {
+                                              uint32_t nchunks, int bits4, int keep_long, int accel) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE * WAYS];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
@@ -494,7 +664,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 ((u32x4 *)s_data)[2 * w + 1] = ob;
             }
         }
-        match_chunk(s_data, sh, len, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, keep_long != 0, lane);
+        match_chunk<WAYS, SNAPPY>(s_data, sh, len, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, keep_long != 0, accel, lane);
     }
 }
 
@@ -504,12 +674,12 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 // elements, and builds the chunk image in LDS.  The TS waves of a block read the same bytes; they are given
 // workgroup ids that are equal mod 8 (same XCD under round-robin placement: they share the L2 lines -- speed
 // only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
-template <int TS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
-                                                    uint8_t *__restrict__ records, uint32_t nblk, uint32_t plane_mask) {
+template <int TS, int WAYS, bool SNAPPY>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 6 : 4))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
+                                                    uint8_t *__restrict__ records, uint32_t nblk, uint32_t plane_mask, int accel) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE * WAYS];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
@@ -572,7 +742,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_
             }
         }
         const uint32_t ck = j * nblk + b;
-        match_chunk(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, lane);
+        match_chunk<WAYS, SNAPPY>(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, accel, lane);
     }
 }
 
@@ -799,8 +969,164 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
 }
 
 // ----------------------------------------------------------------------------------------------
+// Snappy block assembly (codec.go:228-244: snappy.Encode): uvarint(n) + the chunks' element streams, concatenated.
+// A Snappy block has no sequence chain to repair: every chunk's record is already final, so this is a prefix sum + a copy.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uvarint_len(uint64_t v) { uint32_t k = 1; while (v >= 128) { v >>= 7; k++; } return k; }
+
+__global__ __launch_bounds__(256) void k_sn_tiles(const ChunkDesc *__restrict__ desc, uint32_t nchunks, Agg *__restrict__ tile_agg) {
+    __shared__ uint32_t s[256];
+    const int t = threadIdx.x;
+    const uint32_t ck = blockIdx.x * HB_TILE_CHUNKS + t;
+    s[t] = ck < nchunks ? desc[ck].enc_len : 0u;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (t < d) s[t] += s[t + d]; __syncthreads(); }
+    if (t == 0) { Agg a = agg_identity(); a.fixed = s[0]; tile_agg[blockIdx.x] = a; }
+}
+
+// one workgroup: exclusive prefix of the tile sums, total, memcpy decision (blosc.go:342), frame header, result record
+__global__ __launch_bounds__(256) void k_sn_scan(const Agg *__restrict__ tile_agg, Agg *__restrict__ tile_pre, uint32_t ntiles, uint32_t nchunks,
+                                                 uint64_t n, EncPlan *plan, uint8_t *dst, FrameInfo fi, hb_result *result, int has_index) {
+    __shared__ uint64_t s[256];
+    __shared__ uint64_t carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 256) {
+        const uint32_t i = base + t;
+        const uint64_t mine = i < ntiles ? (uint64_t)tile_agg[i].fixed : 0ull;
+        s[t] = mine;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const uint64_t y = t >= d ? s[t - d] : 0ull;
+            __syncthreads();
+            s[t] += y;
+            __syncthreads();
+        }
+        if (i < ntiles) { Agg a = agg_identity(); a.fixed = (int64_t)(carry + s[t] - mine); tile_pre[i] = a; }
+        __syncthreads();
+        if (t == 0) carry += s[255];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const uint32_t hl = uvarint_len(n);
+        const uint64_t C = hl + carry;
+        plan->cbytes_block = C;
+        plan->nchunks = nchunks;
+        const uint32_t use_memcpy = C >= n;                           // blosc.go:342
+        const uint64_t payload = use_memcpy ? n : C;
+        uint8_t flags = 0;                                            // blosc.go:348-356
+        if (fi.shuffle == HB_SHUFFLE) flags |= HB_FLAG_SHUFFLE;
+        else if (fi.shuffle == HB_BITSHUFFLE) flags |= HB_FLAG_BITSHUFFLE;
+        if (use_memcpy) flags |= HB_FLAG_MEMCPY;
+        const uint32_t cbytes = (uint32_t)(HB_HEADER_SIZE + payload);
+        dst[0] = HB_FORMAT_VERSION; dst[1] = (uint8_t)fi.codec; dst[2] = flags; dst[3] = (uint8_t)fi.typesize;   // :358-366
+        ((uint32_t *)dst)[1] = (uint32_t)n; ((uint32_t *)dst)[2] = (uint32_t)n; ((uint32_t *)dst)[3] = cbytes;
+        if (!use_memcpy) {                                            // uvarint(n), little-endian base 128
+            uint64_t v = n; uint8_t *o = dst + HB_HEADER_SIZE;
+            while (v >= 128) { *o++ = (uint8_t)(v | 128u); v >>= 7; }
+            *o = (uint8_t)v;
+        }
+        result->flags = flags; result->bytes = cbytes;
+        uint64_t total = cbytes;
+        plan->index_off = 0;
+        if (has_index && !use_memcpy) {
+            plan->index_off = ((uint64_t)cbytes + 7) & ~7ull;
+            total = plan->index_off + HB_SNX_HDR_BYTES + (uint64_t)HB_SNX_ENTRY * (nchunks + 1);
+            for (uint64_t i = cbytes; i < plan->index_off; i++) dst[i] = 0;
+        }
+        result->total_bytes = total;
+        plan->use_memcpy = use_memcpy;
+        result->status = HB_OK; result->reserved = 0;
+    }
+}
+
+// one workgroup per tile of 256 chunks: every wave copies its chunks' records to their final place; unit index (stream offsets)
+__global__ __launch_bounds__(STITCH_THREADS) void k_sn_pack(const ChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records,
+                                                            const Agg *__restrict__ tile_pre, const EncPlan *__restrict__ plan, uint32_t nchunks,
+                                                            uint64_t n, uint8_t *__restrict__ out /* payload start */, uint8_t *__restrict__ frame_base,
+                                                            const uint8_t *__restrict__ memcpy_src) {
+    __shared__ uint32_t s[256];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    constexpr int NW = STITCH_THREADS / 64;
+    const uint32_t ck0 = blockIdx.x * HB_TILE_CHUNKS;
+    const uint32_t cnt = min(HB_TILE_CHUNKS, nchunks - ck0);
+    if (plan->use_memcpy) {                                           // blosc.go:343-345: payload = (filtered) input
+        const uint64_t b0 = (uint64_t)ck0 * HB_CHUNK, b1 = min((uint64_t)(ck0 + cnt) * HB_CHUNK, n);
+        for (uint64_t off = b0 + (uint64_t)wave * 16384u; off < b1; off += (uint64_t)NW * 16384u)
+            if (memcpy_src) wave_copy_g2g(out + off, memcpy_src + off, (uint32_t)min((uint64_t)16384u, b1 - off), lane);
+        return;
+    }
+    uint32_t mine = 0;
+    if (t < 256) { mine = (uint32_t)t < cnt ? desc[ck0 + t].enc_len : 0u; s[t] = mine; }
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                               // inclusive prefix within the tile
+        uint32_t y = 0;
+        if (t < 256 && t >= d) y = s[t - d];
+        __syncthreads();
+        if (t < 256) s[t] += y;
+        __syncthreads();
+    }
+    const uint32_t hl = uvarint_len(n);
+    const uint64_t tbase = (uint64_t)hl + (uint64_t)tile_pre[blockIdx.x].fixed;
+    uint8_t *index = (frame_base && plan->index_off) ? frame_base + plan->index_off : nullptr;
+    for (uint32_t c = wave; c < cnt; c += NW) {
+        const uint32_t ck = ck0 + c;
+        const uint32_t incl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s[c]);
+        const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)desc[ck].enc_len);
+        const uint64_t O = tbase + incl - len;
+        wave_copy_g2g(out + O, records + (size_t)ck * HB_RSTRIDE, len, lane);
+        if (index && lane == 0) {
+            uint32_t *e = (uint32_t *)(index + HB_SNX_HDR_BYTES);
+            e[ck] = (uint32_t)O;
+            if (ck + 1 == nchunks) {
+                e[nchunks] = (uint32_t)plan->cbytes_block;
+                uint32_t *h = (uint32_t *)index;
+                h[0] = HB_SNX_MAGIC; h[1] = HB_IDX_VERSION | (HB_SNX_ENTRY << 16); h[2] = nchunks; h[3] = HB_CHUNK;
+                h[4] = (uint32_t)plan->cbytes_block; h[5] = (uint32_t)n; h[6] = hl;
+                h[7] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5] ^ h[6];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // launch
 // ----------------------------------------------------------------------------------------------
+// Search depth and skip acceleration from (codec, level).  LZ4: one candidate (lz4.CompressBlock); the reference ignores the level
+// there (codec.go:63-66), here it is a speed knob that never changes validity: 1-3 skip harder, 4-6 the default, 7-9 no skipping.
+// LZ4HC: codec.go:96-106 maps level <= 3 / <= 5 / <= 7 / else to lz4.Level1 / 5 / 7 / 9; here 1 / 2 / 4 / 4 candidates per
+// bucket, no skipping.  Snappy has no levels (codec.go:232-235).
+static inline void enc_policy(const hb_enc_args &a, int &ways, int &accel) {
+    const int level = a.level < 1 ? 1 : (a.level > 9 ? 9 : a.level);          // blosc.go:277-282
+    ways = 1; accel = 64;
+    if (a.codec == HB_LZ4HC) { ways = level <= 3 ? 1 : (level <= 5 ? 2 : 4); accel = 0; }
+    else if (a.codec == HB_LZ4 && a.frame) accel = level <= 3 ? 128 : (level <= 6 ? 64 : 0);
+}
+
+#define HB_LAUNCH_FUSED(TS, W, SN) hipLaunchKernelGGL((k_match_fused<TS, W, SN>), dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask(), accel)
+static void launch_match_fused(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, uint8_t *records, uint32_t nblk, hipStream_t s) {
+    int ways, accel;
+    enc_policy(a, ways, accel);
+    const bool sn = a.codec == HB_SNAPPY;
+    switch (a.fused_ts) {
+    case 2: if (sn) HB_LAUNCH_FUSED(2, 1, true); else if (ways == 1) HB_LAUNCH_FUSED(2, 1, false); else if (ways == 2) HB_LAUNCH_FUSED(2, 2, false); else HB_LAUNCH_FUSED(2, 4, false); break;
+    case 4: if (sn) HB_LAUNCH_FUSED(4, 1, true); else if (ways == 1) HB_LAUNCH_FUSED(4, 1, false); else if (ways == 2) HB_LAUNCH_FUSED(4, 2, false); else HB_LAUNCH_FUSED(4, 4, false); break;
+    default: if (sn) HB_LAUNCH_FUSED(8, 1, true); else if (ways == 1) HB_LAUNCH_FUSED(8, 1, false); else if (ways == 2) HB_LAUNCH_FUSED(8, 2, false); else HB_LAUNCH_FUSED(8, 4, false); break;
+    }
+}
+#define HB_LAUNCH_MATCH(W, SN) hipLaunchKernelGGL((k_match<W, SN>), dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, nchunks, a.fused_bits, keep_long, accel)
+static void launch_match(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, uint8_t *records, uint32_t nchunks, hipStream_t s) {
+    int ways, accel;
+    enc_policy(a, ways, accel);
+    // byte-shuffled frames keep the fused kernels' table policy, fused or not (identical frames either way)
+    const int keep_long = (a.frame && a.shuffle == HB_SHUFFLE && a.typesize > 1) ? 0 : 1;
+    if (a.codec == HB_SNAPPY) HB_LAUNCH_MATCH(1, true);
+    else if (ways == 1) HB_LAUNCH_MATCH(1, false);
+    else if (ways == 2) HB_LAUNCH_MATCH(2, false);
+    else HB_LAUNCH_MATCH(4, false);
+}
+
 int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
     const EncLayout L = enc_layout(a.n);
     uint8_t *w = a.work;
@@ -829,21 +1155,35 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
                 if (grid > 256u * 256u) grid = 256u * 256u;
                 if (grid == 0) grid = L.nchunks;
             }
-            switch (a.fused_ts) {
-            case 2: hipLaunchKernelGGL(k_match_fused<2>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask()); break;
-            case 4: hipLaunchKernelGGL(k_match_fused<4>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask()); break;
-            default: hipLaunchKernelGGL(k_match_fused<8>, dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask()); break;
-            }
+            launch_match_fused(a, grid, desc, records, nblk, s);
         } else {
             const unsigned grid = L.nchunks < 256u * 256u ? L.nchunks : 256u * 256u;
-            // byte-shuffled frames keep the fused kernels' table policy, fused or not (identical frames either way)
-            hipLaunchKernelGGL(k_match, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, L.nchunks, a.fused_bits,
-                               (a.frame && a.shuffle == HB_SHUFFLE && a.typesize > 1) ? 0 : 1);
+            launch_match(a, grid, desc, records, L.nchunks, s);
         }
         hb_prof_end(s);
-        hb_prof_begin("k_tiles", s);
-        hipLaunchKernelGGL(k_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg, tile_nf);
+        if (a.codec == HB_SNAPPY) {
+            hb_prof_begin("k_sn_tiles", s);
+            hipLaunchKernelGGL(k_sn_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg);
+            hb_prof_end(s);
+        } else {
+            hb_prof_begin("k_tiles", s);
+            hipLaunchKernelGGL(k_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg, tile_nf);
+            hb_prof_end(s);
+        }
+    }
+    if (a.codec == HB_SNAPPY) {                                        // (frame only; n > 0)
+        hb_prof_begin("k_sn_scan", s);
+        hipLaunchKernelGGL(k_sn_scan, dim3(1), dim3(256), 0, s, tile_agg, tile_pre, L.ntiles, L.nchunks, (uint64_t)a.n, plan, a.dst, fi, a.result, has_index);
         hb_prof_end(s);
+        if ((a.fused_ts || a.fused_bits) && !a.memcpy_src) {
+            const int rc = hb_launch_filter_gated(a.fused_bits ? HB_OP_BITSHUFFLE : HB_OP_SHUFFLE, out, a.src, a.n, a.fused_bits ? a.fused_bits : a.fused_ts, &plan->use_memcpy, s);
+            if (rc) return rc;
+        }
+        hb_prof_begin("k_sn_pack", s);
+        hipLaunchKernelGGL(k_sn_pack, dim3(L.ntiles), dim3(STITCH_THREADS), 0, s, desc, records, tile_pre, plan, L.nchunks, (uint64_t)a.n, out, a.dst, a.memcpy_src);
+        hb_prof_end(s);
+        HB_HIP_TRY(hipGetLastError());
+        return HB_OK;
     }
     hb_prof_begin("k_scan", s);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, s, tile_agg, tile_nf, tile_pre, tile_suf, L.ntiles, L.nchunks,

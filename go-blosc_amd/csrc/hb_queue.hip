@@ -133,7 +133,7 @@ int64_t hb_queue_compress(hb_queue *q, const void *src, size_t n, void *dst, siz
     if (!q) return HB_ERR_BAD_ARG;
     if (n == 0) return HB_ERR_INVALID_DATA;                               // blosc.go:269-271
     if (!src || !dst) return HB_ERR_BAD_ARG;
-    if (codec != HB_LZ4) return HB_ERR_INVALID_CODEC;                     // blosc.go:322-325; the queue carries the device codec only
+    if (!hb_device_codec(codec)) return HB_ERR_INVALID_CODEC;             // blosc.go:322-325; the queue carries the device codecs only
     if (n > q->max_n) return HB_ERR_DATA_TOO_LARGE;
     if (hipSetDevice(q->device) != hipSuccess) return HB_ERR_HIP;
     int64_t ticket;
@@ -157,7 +157,7 @@ int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst,
     int rc = hb_parse_header(frame, n, &h);                               // the frame is in host memory: no read-back
     if (rc) return rc;
     if ((size_t)h.cbytes > n || h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;           // blosc.go:385-390
-    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_LZ4 && h.codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;
+    if (!(h.flags & HB_FLAG_MEMCPY) && !hb_device_codec(h.codec)) return HB_ERR_INVALID_CODEC;
     if ((size_t)h.nbytes > q->max_n || n > q->in_bytes) return HB_ERR_DATA_TOO_LARGE;
     if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
     if (hipSetDevice(q->device) != hipSuccess) return HB_ERR_HIP;
@@ -227,12 +227,12 @@ int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *
     for (int d = 0; d < nd && d < nframes; d++) {
         th.emplace_back([=]() {
             size_t max_n = 0;
-            if (codec == HB_LZ4)
+            if (hb_device_codec(codec))
                 for (int k = d; k < nframes; k += nd)
                     if (n[k] <= 0xFFFFFFFFull - HB_HEADER_SIZE - n[k] / 255 - 64) max_n = std::max(max_n, n[k]);
             run_device(d, nd, nframes, max_n, rc,
                        [&](hb_queue *q, int k) -> int64_t {
-                           if (codec != HB_LZ4 || !src[k] || !dst[k] || n[k] == 0) return HB_ERR_BAD_ARG;
+                           if (!hb_device_codec(codec) || !src[k] || !dst[k] || n[k] == 0) return HB_ERR_BAD_ARG;
                            return hb_queue_compress(q, src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts);
                        },
                        [&](int k, int dev) { return hb_compress_frame(src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts, dev); });
@@ -253,7 +253,7 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
             size_t max_n = 0;                              // largest decoded size among this device's well-formed LZ4 frames
             for (int k = d; k < nframes; k += nd) {
                 hb_header h;
-                if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (h.codec == HB_LZ4 || h.codec == HB_LZ4HC || (h.flags & HB_FLAG_MEMCPY)))
+                if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (hb_device_codec(h.codec) || (h.flags & HB_FLAG_MEMCPY)))
                     max_n = std::max(max_n, std::max<size_t>(h.nbytes, 1));
             }
             if (max_n > 0xFFFFFFFFull - HB_HEADER_SIZE - max_n / 255 - 64) max_n = 0;

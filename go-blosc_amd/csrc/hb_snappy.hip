@@ -1,0 +1,386 @@
+// hb_snappy.hip — Snappy block decoder for gfx950: replaces snappyCodec.Decompress (codec.go:237-244, i.e. snappy.Decode of
+// klauspost/compress v1.18.2, which is not in the reference tree) on the device.  The encoder side is the LZ4 matcher with a
+// Snappy emitter (hb_lz4_enc.hip: match_chunk<1, true>, k_sn_tiles / k_sn_scan / k_sn_pack).
+//
+// Block format (Snappy format_description.txt): uvarint(decoded length), then elements.  Tag byte, low two bits:
+//   00 literal : len-1 = tag >> 2 if < 60, else 60..63 -> the next 1..4 bytes hold len-1 (little endian)
+//   01 copy    : len = 4 + ((tag >> 2) & 7), offset = (tag >> 5) << 8 | next byte          (2 bytes)
+//   10 copy    : len = 1 + (tag >> 2), offset = next 2 bytes                               (3 bytes)
+//   11 copy    : len = 1 + (tag >> 2), offset = next 4 bytes                               (5 bytes)
+// Decoder contract restated from the format + the Go decoder's published behaviour: offset 0, offset beyond the bytes produced,
+// an element running past the input, output beyond the declared length, or fewer bytes than declared -> corrupt
+// (-> ErrDecompressionFailed, blosc.go:411-413); the result always has the DECLARED length, which the frame layer then compares
+// with NBytesOrig (ErrSizeMismatch, blosc.go:429-431).  NOT restated: S2's "repeat offset" reading of a 1-byte-offset copy with
+// offset 0 (a klauspost extension that no Snappy encoder emits); such an element is corrupt here.
+//
+//   k_sn_dec_indexed : blocks with a unit index (HBSX, hb_format.h) -- every block this library encodes.  One wavefront per
+//       4 KiB unit of output, the unit's slice of the stream staged in LDS; 64 lanes parse 64 stream bytes "as if an element
+//       started at my byte", the real chain is followed with one s_bitset1 + one v_readlane per element, elements are queued and
+//       copied one per lane by the machinery shared with the LZ4 decoder (hb_dec_common.h: a literal element is a token without
+//       a match, a copy a token without literals).  The index is not trusted: a unit must consume exactly its slice and
+//       produce exactly its 4 KiB, and no copy may reach before the unit; anything else raises a flag ...
+//   k_sn_dec_serial  : ... and the whole block is decoded by one wavefront front to back (also: blocks without an index, e.g.
+//       written by the reference): 64 KiB of history in LDS, copies that reach further back read the output in HBM.
+#include "hb_lz4.h"
+#include "hb_dec_common.h"
+
+struct SnPlan {
+    uint32_t mode;        // 0 = serial, 1 = indexed
+    uint32_t fail;
+    uint32_t nunits;
+    uint32_t nbytes;      // declared (uvarint) length
+    uint32_t hdr;         // bytes of the uvarint
+    uint32_t pad[3];
+};
+
+#define SN_IN_MAX 4608u      // largest unit slice the indexed decoder stages (4096 literal bytes + headers + slack)
+
+__device__ __forceinline__ bool sn_uvarint(const uint8_t *src, uint64_t n, uint64_t &v, uint32_t &used) {
+    v = 0;
+    for (uint32_t i = 0; i < 10u && i < n; i++) {
+        const uint32_t b = src[i];
+        v |= (uint64_t)(b & 127u) << (7u * i);
+        if (!(b & 128u)) { used = i + 1u; return !(i == 9u && b > 1u); }
+    }
+    return false;
+}
+
+__global__ void k_sn_dec_plan(const uint8_t *__restrict__ src, uint64_t n_src, const uint8_t *__restrict__ index, uint64_t index_bytes,
+                              uint64_t cap, SnPlan *plan, hb_result *result) {
+    plan->mode = 0; plan->fail = 0; plan->nunits = 0; plan->nbytes = 0; plan->hdr = 0;
+    result->status = HB_OK; result->flags = 0; result->bytes = 0; result->total_bytes = 0; result->reserved = 0;
+    uint64_t dlen; uint32_t hl;
+    if (!sn_uvarint(src, n_src, dlen, hl) || dlen > 0xFFFFFFFFull) return;      // the serial kernel reports the error
+    if (!index || index_bytes < HB_SNX_HDR_BYTES + 2 * HB_SNX_ENTRY) return;
+    uint32_t h[8];
+    for (int i = 0; i < 8; i++) h[i] = ld4u(index + 4 * i);
+    if (h[0] != HB_SNX_MAGIC || h[1] != (HB_IDX_VERSION | (HB_SNX_ENTRY << 16))) return;
+    if (h[7] != (h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5] ^ h[6])) return;
+    const uint64_t nunits = h[2];
+    if (nunits == 0 || HB_SNX_HDR_BYTES + (nunits + 1) * HB_SNX_ENTRY > index_bytes) return;
+    if (h[3] != HB_CHUNK || nunits != ((uint64_t)h[5] + HB_CHUNK - 1) / HB_CHUNK) return;     // one unit per 4 KiB of output, exactly
+    if (h[4] != n_src || h[5] != dlen || dlen > cap || h[6] != hl) return;
+    plan->nunits = (uint32_t)nunits; plan->nbytes = (uint32_t)dlen; plan->hdr = hl;
+    plan->mode = 1;
+}
+
+// FILL: 64 lanes parse 64 stream bytes "as if an element started at my byte"; the real chain is walked on the scalar side.
+// Elements go to s_tq as {lsrc | lit << 13 | mlen << 22, offset | pos << 16}.  Returns true when it stopped at the end of the
+// slice or at an element the lane-parallel path does not take (literal longer than 511 bytes, 4-byte offset, too close to lim).
+__device__ __forceinline__ bool sn_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq,
+                                        uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si == lim) { stop = true; break; }
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t w = dec_read4(s_in, sh + p);
+        const uint32_t t = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, kind = t & 3u, x = t >> 2;
+        bool cplx = p >= lim;
+        uint32_t lit = 0, mlen = 0, offv = 0, hdr = 1;
+        if (kind == 0u) {
+            if (x < 60u) lit = x + 1u;
+            else if (x == 60u) { lit = b1 + 1u; hdr = 2u; }
+            else if (x == 61u) { lit = (b1 | (b2 << 8)) + 1u; hdr = 3u; }
+            else cplx = true;
+            if (lit > 511u) cplx = true;
+        } else if (kind == 1u) { mlen = 4u + (x & 7u); offv = ((t >> 5) << 8) | b1; hdr = 2u; }
+        else if (kind == 2u) { mlen = 1u + x; offv = b1 | (b2 << 8); hdr = 3u; }
+        else cplx = true;
+        const uint32_t lsrc = p + hdr, nxt = lsrc + lit;
+        if (nxt > lim) cplx = true;
+        const unsigned long long cmask = hb_ballot(cplx);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const uint32_t nrel = cplx ? 64u : nxt - base;
+            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
+            uint32_t j = 0, lastj;
+            for (;;) {
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            const unsigned long long cm = tmask & cmask;
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) {
+            uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
+            s_tq[nq + rank] = e;
+        }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+    }
+    return stop;
+}
+
+// one element the slow way, all values wave-uniform: returns false on a malformed element.  `in[k]` = stream byte k of a
+// buffer holding `avail` bytes from position 0.  kind / lit / mlen / off / hdr describe the element at `at`.
+struct SnElem { uint32_t kind, hdr; uint64_t lit; uint32_t mlen; uint64_t off; };
+__device__ __forceinline__ bool sn_parse_uniform(const uint8_t *p, uint64_t avail, SnElem &e) {
+    if (avail < 1) return false;
+    const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)p[0]);
+    e.kind = t & 3u; e.lit = 0; e.mlen = 0; e.off = 0; e.hdr = 1;
+    const uint32_t x = t >> 2;
+    auto byte = [&](uint32_t i) { return (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)p[i]); };
+    if (e.kind == 0u) {
+        if (x < 60u) e.lit = x + 1u;
+        else {
+            const uint32_t nb = x - 59u;                          // 1..4 length bytes
+            if (avail < 1u + nb) return false;
+            uint64_t v = 0;
+            for (uint32_t i = 0; i < nb; i++) v |= byte(1u + i) << (8u * i);
+            e.lit = v + 1u; e.hdr = 1u + nb;
+        }
+    } else if (e.kind == 1u) { if (avail < 2) return false; e.mlen = 4u + (x & 7u); e.off = ((uint64_t)(t >> 5) << 8) | byte(1); e.hdr = 2; }
+    else if (e.kind == 2u) { if (avail < 3) return false; e.mlen = 1u + x; e.off = byte(1) | (byte(2) << 8); e.hdr = 3; }
+    else { if (avail < 5) return false; e.mlen = 1u + x; e.off = byte(1) | (byte(2) << 8) | (byte(3) << 16) | (byte(4) << 24); e.hdr = 5; }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_sn_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src, uint8_t *__restrict__ dst,
+                                                       const uint8_t *__restrict__ index, SnPlan *plan) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[SN_IN_MAX + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[HB_CHUNK + 64];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    if (plan->mode != 1) return;
+    const int lane = threadIdx.x;
+    const uint32_t nunits = plan->nunits, nbytes = plan->nbytes, hl = plan->hdr;
+    const uint8_t *ent = index + HB_SNX_HDR_BYTES;
+    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+        const uint32_t s0 = RFL(ld4u(ent + 4 * (size_t)u)), s1 = RFL(ld4u(ent + 4 * (size_t)(u + 1)));
+        const uint32_t d0 = u * HB_CHUNK, outlen = min(HB_CHUNK, nbytes - d0);
+        bool ok = s0 >= hl && s0 <= s1 && s1 <= n_src && (s1 - s0) <= SN_IN_MAX;
+        if (u == 0) ok = ok && s0 == hl;
+        if (u + 1 == nunits) ok = ok && s1 == n_src;
+        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
+        const uint32_t slen = s1 - s0;
+        const uint8_t *g = src + s0;
+        const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
+        wave_sync();
+        {
+            const u32x4 *ga = (const u32x4 *)(g - sh);
+            const uint32_t nv = (sh + slen + 15u) >> 4;
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_in)[i] = ga[i];
+        }
+        wave_sync();
+        uint32_t si = 0, di = 0, nq = 0;
+        bool done = false;
+        while (ok && !done) {
+            const bool stop = sn_fill(s_in, sh, slen, si, nq, s_tq, lane);
+            bool rewound = false;
+            ok = dec_drain(s_in, (int)sh, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
+            if (!ok || rewound) { ok = false; break; }            // an element that passes the end of the unit: not ours to decide
+            if (stop) {
+                if (si == slen) { done = true; break; }
+                SnElem e;                                        // one element the slow way: a literal longer than 511 bytes
+                if (!sn_parse_uniform(s_in + sh + si, slen - si, e) || e.kind != 0u) { ok = false; break; }
+                if (e.lit > (uint64_t)(slen - si - e.hdr) || e.lit > (uint64_t)(outlen - di)) { ok = false; break; }
+                const uint32_t ls = sh + si + e.hdr, ln = (uint32_t)e.lit;
+                for (uint32_t k = lane; k < ln; k += 64) s_out[di + k] = s_in[ls + k];
+                si += e.hdr + ln; di += ln;
+                wave_sync();
+            }
+        }
+        if (ok) ok = (si == slen) && (di == outlen);
+        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); wave_sync(); continue; }
+        wave_sync();
+        uint8_t *o = dst + d0;                                    // flush the unit image: 16-byte stores on an aligned body
+        uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);
+        if (head > outlen) head = outlen;
+        if ((uint32_t)lane < head) o[lane] = s_out[lane];
+        const uint32_t body = (outlen - head) >> 4;
+        if (head == 0) { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + i * 16u) = *(const u32x4 *)(s_out + i * 16u); }
+        else {
+            for (uint32_t i = lane; i < body; i += 64) {
+                const uint8_t *q = s_out + head + i * 16u;
+                u32x4 v;
+                v.x = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                v.y = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+                v.z = (uint32_t)q[8] | ((uint32_t)q[9] << 8) | ((uint32_t)q[10] << 16) | ((uint32_t)q[11] << 24);
+                v.w = (uint32_t)q[12] | ((uint32_t)q[13] << 8) | ((uint32_t)q[14] << 16) | ((uint32_t)q[15] << 24);
+                *(u32x4 *)(o + head + i * 16u) = v;
+            }
+        }
+        const uint32_t done_b = head + body * 16u;
+        if (done_b + lane < outlen) o[done_b + lane] = s_out[done_b + lane];
+        wave_sync();
+#undef RFL
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_sn_dec_serial: one wavefront, whole block, front to back
+// ------------------------------------------------------------------------------------------------------------
+#define SNS_WIN   8192u
+#define SNS_HIST  65536u
+#define SNS_PAGE  32768u
+#define SNS_SOFT  16384u
+
+__global__ __launch_bounds__(64) void k_sn_dec_serial(const uint8_t *__restrict__ src, uint64_t n_src, uint8_t *__restrict__ dst, uint64_t cap,
+                                                      SnPlan *plan, hb_result *result, int frame, uint32_t expect) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[SNS_WIN + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[SNS_HIST + SNS_PAGE + 1024];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    const int lane = threadIdx.x;
+    if (plan->mode == 1 && !plan->fail) {
+        if (lane == 0) {
+            const uint64_t got = plan->nbytes;
+            result->flags = 1; result->bytes = got; result->total_bytes = got;
+            result->status = (frame && got != expect) ? HB_ERR_SIZE_MISMATCH : HB_OK;      // blosc.go:429-431
+        }
+        return;
+    }
+    int err = 0;
+    uint64_t dlen = 0; uint32_t hl = 0;
+    if (!sn_uvarint(src, n_src, dlen, hl) || dlen > 0xFFFFFFFFull) err = 1;
+    if (!err && dlen > cap) {
+        // more declared bytes than the caller's buffer (the frame's NBytesOrig): the reference decodes into a buffer of its
+        // own and the frame layer then reports ErrSizeMismatch; without that buffer the stream cannot be validated here
+        if (lane == 0) { result->flags = 0; result->total_bytes = 0; result->bytes = dlen; result->status = frame ? HB_ERR_SIZE_MISMATCH : HB_ERR_SHORT_BUFFER; }
+        return;
+    }
+    uint8_t *out = s_img + SNS_HIST;
+    uint64_t gbase = 0, si = hl, wpos = 0;
+    uint32_t di = 0, wlen = 0, wsh = 0, nq = 0;
+    auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+        const uint8_t *g = src + at;
+        wsh = (uint32_t)((uintptr_t)g & 15u);
+        const uint64_t left = n_src - at;
+        wlen = (uint32_t)(left < (uint64_t)(SNS_WIN - 16u) ? left : (uint64_t)(SNS_WIN - 16u));
+        const u32x4 *ga = (const u32x4 *)(g - wsh);
+        const uint32_t nv = (wsh + wlen + 15u) >> 4;
+        wave_sync();
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+        wpos = at;
+        wave_sync();
+    };
+    auto flush = [&](bool all) __attribute__((always_inline)) {
+        const uint32_t fl = all ? di : (di & ~15u);
+        if (fl == 0) return;
+        wave_sync();
+        uint8_t *o = dst + gbase;
+        for (uint32_t i = lane * 16u; i + 16u <= fl; i += 1024u) st16u(o + i, *(const u32x4 *)(out + i));
+        const uint32_t tail0 = fl & ~15u;
+        if (tail0 + lane < fl) o[tail0 + lane] = out[tail0 + lane];
+        if (!all) {
+            const uint32_t mv = SNS_HIST + (di - fl);
+            for (uint32_t k = lane * 16u; k < mv; k += 1024u) { const u32x4 v = *(const u32x4 *)(s_img + fl + k); *(u32x4 *)(s_img + k) = v; }
+            wave_sync();
+        }
+        gbase += fl; di -= fl;
+    };
+    bool fin = false;
+    if (!err) { if (si < n_src) refill(si); else fin = true; }
+    while (!err && !fin) {
+        if (gbase + di > dlen) { err = 1; break; }
+        if (di >= SNS_SOFT) flush(false);
+        if (si == n_src) { fin = true; break; }
+        if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+        uint32_t rel = (uint32_t)(si - wpos);
+        const uint32_t hist = (uint32_t)(gbase < (uint64_t)SNS_HIST ? gbase : (uint64_t)SNS_HIST);
+        // ---- fast path: window-parallel parse, lane-parallel copies (offsets inside the LDS history) ----
+        const uint64_t left_out = dlen - gbase;
+        const uint32_t room = (uint32_t)(left_out < (uint64_t)SNS_PAGE ? left_out : (uint64_t)SNS_PAGE);
+        const bool stop = sn_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
+        bool rewound = false;
+        const uint32_t di0 = di;
+        const bool dok = dec_drain(s_win + wsh, 0, out, room, hist, di, rel, nq, s_tq, true, rewound, lane);
+        const bool moved = (wpos + rel) != si;
+        if (!dok) {
+            // a copy that reaches beyond the LDS history (> 64 KiB back) or is malformed: decided one element at a time below,
+            // from the first element of the batch (the batch copied nothing that later elements could not overwrite again)
+            di = di0; nq = 0;
+        } else {
+            si = wpos + rel;
+            if (rewound) {                                       // an element that does not fit: the page is full, or it passes the declared length
+                if (room < SNS_PAGE) { err = 1; break; }
+                flush(false);
+                continue;
+            }
+            else if (moved && !stop) continue;
+            else if (si == n_src) { fin = true; break; }
+            else if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src) continue;     // stopped at the window edge: refill first
+        }
+        // ---- one element the slow way: literal of any size, copy with any offset ----
+        if (si < wpos || si - wpos + 8u > wlen) refill(si);
+        rel = (uint32_t)(si - wpos);
+        SnElem e;
+        if (!sn_parse_uniform(s_win + wsh + rel, n_src - si, e)) { err = 1; break; }
+        si += e.hdr;
+        if (e.kind == 0u) {
+            if (e.lit > n_src - si || e.lit > dlen - (gbase + di)) { err = 1; break; }
+            uint64_t lrem = e.lit;
+            while (lrem) {
+                const uint32_t rm = SNS_PAGE - di;
+                const uint32_t take = (uint32_t)(lrem < (uint64_t)rm ? lrem : (uint64_t)rm);
+                if (take == 0) { flush(false); continue; }
+                const uint8_t *g = src + si;
+                uint32_t k0 = 0;
+                for (; k0 + 4096u <= take; k0 += 4096u) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = ld16u(g + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ((hb_u128u *)(out + di + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u))->v = v[q];
+                }
+                for (uint32_t k = k0 + lane; k < take; k += 64) out[di + k] = g[k];
+                si += take; di += take; lrem -= take;
+                wave_sync();
+                if (di >= SNS_SOFT) flush(false);
+            }
+        } else {
+            const uint64_t produced = gbase + di;
+            if (e.off == 0 || e.off > produced || (uint64_t)e.mlen > dlen - produced) { err = 1; break; }
+            if (SNS_PAGE - di < e.mlen) flush(false);
+            if (e.off <= (uint64_t)di + hist) {
+                wave_sync();
+                dec_match_copy(out, di, (uint32_t)e.off, e.mlen, lane);
+            } else {
+                // beyond the LDS history: the source lies in output this wave flushed to HBM long ago (off > 64 KiB >= mlen: no overlap)
+                const uint8_t *gs = dst + (produced - e.off);
+                if ((uint32_t)lane < e.mlen) out[di + lane] = __builtin_nontemporal_load(gs + lane);
+            }
+            di += e.mlen;
+            wave_sync();
+        }
+    }
+    if (!err && gbase + di != dlen) err = 1;                           // fewer (or more) bytes than declared
+    if (!err) flush(true);
+    if (lane == 0) {
+        result->flags = 0; result->total_bytes = 0;
+        if (err) { result->status = HB_ERR_DECOMPRESSION_FAILED; result->bytes = 0; }                       // blosc.go:411-413
+        else if (frame && dlen != expect) { result->status = HB_ERR_SIZE_MISMATCH; result->bytes = dlen; }    // blosc.go:429-431
+        else { result->status = HB_OK; result->bytes = dlen; }
+    }
+}
+
+size_t hb_snappy_dec_workspace(size_t) { return 256; }
+
+int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
+    SnPlan *plan = (SnPlan *)a.work;
+    hb_prof_begin("k_sn_dec_plan", s);
+    hipLaunchKernelGGL(k_sn_dec_plan, dim3(1), dim3(1), 0, s, a.src, (uint64_t)a.n, a.index, (uint64_t)a.index_bytes, (uint64_t)a.cap, plan, a.result);
+    hb_prof_end(s);
+    if (a.index) {
+        const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
+        const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 256u ? units : 256u * 256u));
+        hb_prof_begin("k_sn_dec_indexed", s);
+        hipLaunchKernelGGL(k_sn_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan);
+        hb_prof_end(s);
+    }
+    hb_prof_begin("k_sn_dec_serial", s);
+    hipLaunchKernelGGL(k_sn_dec_serial, dim3(1), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (uint64_t)a.cap, plan, a.result, a.frame, a.expect);
+    hb_prof_end(s);
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}

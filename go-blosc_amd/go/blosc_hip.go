@@ -39,9 +39,10 @@ var Device = 0
 var ForceDeviceDecode = false
 
 // hasRestartIndex: is there an "HBIX" index after NBytesComp (written by CompressHIP(..., withIndex=true))?
+// (the LZ4 / LZ4HC trailer starts with "HBIX", the Snappy one with "HBSX": include/hipblosc.h, csrc/hb_format.h)
 func hasRestartIndex(data []byte, h *Header) bool {
 	off := (int(h.NBytesComp) + 7) &^ 7
-	return len(data) >= off+64 && string(data[off:off+4]) == "HBIX"
+	return len(data) >= off+40 && (string(data[off:off+4]) == "HBIX" || string(data[off:off+4]) == "HBSX")
 }
 
 var useHIP bool
@@ -148,7 +149,8 @@ func CompressHIP(data []byte, opts Options, withIndex bool) ([]byte, error) {
 	if len(data) == 0 {
 		return nil, ErrInvalidData // blosc.go:269-271
 	}
-	if !useHIP || opts.Codec != LZ4 || len(data) < MinOffloadBytes {
+	// device codecs: LZ4 (codec.go:59-84), LZ4HC (codec.go:90-128: the level picks the search depth) and Snappy (codec.go:228-244)
+	if !useHIP || !deviceCodec(opts.Codec) || len(data) < MinOffloadBytes {
 		return CompressWithOptions(data, opts)
 	}
 	var o C.uint
@@ -164,6 +166,8 @@ func CompressHIP(data []byte, opts Options, withIndex bool) ([]byte, error) {
 	return buf[:n], nil
 }
 
+func deviceCodec(c Codec) bool { return c == LZ4 || c == LZ4HC || c == Snappy }
+
 // DecompressHIP has DecompressWithSize's semantics (blosc.go:296-303).
 func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 	if len(data) < HeaderSize {
@@ -173,7 +177,7 @@ func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 	if err != nil {
 		return nil, err
 	}
-	if !useHIP || int(h.NBytesOrig) < MinOffloadBytes || (!h.IsMemcpy() && Codec(h.VersionLZ) != LZ4 && Codec(h.VersionLZ) != LZ4HC) {
+	if !useHIP || int(h.NBytesOrig) < MinOffloadBytes || (!h.IsMemcpy() && !deviceCodec(Codec(h.VersionLZ))) {
 		return DecompressWithSize(data, typeSize)
 	}
 	// An LZ4 block is one serial chain: without the restart index the device can only put ONE wavefront on it

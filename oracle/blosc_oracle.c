@@ -250,6 +250,138 @@ int64_t ob_lz4_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap
 }
 
 /* ------------------------------------------------------------------------- */
+/* Snappy block codec — codec.go:228-244 calls snappy.Encode / snappy.Decode   */
+/* of github.com/klauspost/compress v1.18.2 (go.mod:6), NOT in the reference  */
+/* tree.  Restated from the published Snappy block format                     */
+/* (format_description.txt) and the published greedy block encoder of the Go  */
+/* snappy package (64 KiB blocks, 14-bit hash of 4 bytes, skip heuristic,     */
+/* emitLiteral / emitCopy): compressed bytes are PARITY UNPINNED; what is     */
+/* pinned is the format (cross-checked against libsnappy 1.1.8 in tests).     */
+/* Not restated: S2's repeat-offset extension (copy with 1-byte offset 0).    */
+/* ------------------------------------------------------------------------- */
+
+size_t ob_snappy_bound(size_t n) { return 32 + n + n / 6; }      /* snappy.MaxEncodedLen */
+
+static size_t sn_put_uvarint(uint8_t *d, uint64_t v) { size_t i = 0; while (v >= 128) { d[i++] = (uint8_t)(v | 128); v >>= 7; } d[i++] = (uint8_t)v; return i; }
+
+static size_t sn_emit_literal(uint8_t *d, const uint8_t *lit, size_t n) {
+    size_t i = 0; const size_t x = n - 1;
+    if (x < 60) d[i++] = (uint8_t)(x << 2);
+    else if (x < 256) { d[i++] = 60 << 2; d[i++] = (uint8_t)x; }
+    else if (x < 65536) { d[i++] = 61 << 2; d[i++] = (uint8_t)x; d[i++] = (uint8_t)(x >> 8); }
+    else if (x < 16777216) { d[i++] = 62 << 2; d[i++] = (uint8_t)x; d[i++] = (uint8_t)(x >> 8); d[i++] = (uint8_t)(x >> 16); }
+    else { d[i++] = 63 << 2; d[i++] = (uint8_t)x; d[i++] = (uint8_t)(x >> 8); d[i++] = (uint8_t)(x >> 16); d[i++] = (uint8_t)(x >> 24); }
+    memcpy(d + i, lit, n);
+    return i + n;
+}
+static size_t sn_emit_copy(uint8_t *d, size_t offset, size_t length) {
+    size_t i = 0;
+    while (length >= 68) { d[i++] = 63 << 2 | 2; d[i++] = (uint8_t)offset; d[i++] = (uint8_t)(offset >> 8); length -= 64; }
+    if (length > 64) { d[i++] = 59 << 2 | 2; d[i++] = (uint8_t)offset; d[i++] = (uint8_t)(offset >> 8); length -= 60; }
+    if (length >= 12 || offset >= 2048) { d[i++] = (uint8_t)((length - 1) << 2 | 2); d[i++] = (uint8_t)offset; d[i++] = (uint8_t)(offset >> 8); }
+    else { d[i++] = (uint8_t)((offset >> 8) << 5 | (length - 4) << 2 | 1); d[i++] = (uint8_t)offset; }
+    return i;
+}
+/* encodeBlock of the Go snappy package on one block of <= 65536 bytes (offsets fit 16 bits) */
+static size_t sn_encode_block(uint8_t *dst, const uint8_t *src, size_t n) {
+    enum { TBITS = 14 };
+    uint16_t table[1 << TBITS];
+    memset(table, 0, sizeof table);
+    size_t d = 0;
+    if (n < 17) return sn_emit_literal(dst, src, n);              /* minNonLiteralBlockSize */
+    const size_t slimit = n - 15;                                 /* inputMargin */
+    size_t lit = 0, s = 1;
+    uint32_t h = (rd32(src + s) * 0x1e35a7bdu) >> (32 - TBITS);
+    for (;;) {
+        size_t skip = 32, next_s = s, cand = 0;
+        for (;;) {
+            s = next_s;
+            const size_t step = skip >> 5;
+            next_s = s + step; skip += step;
+            if (next_s > slimit) goto remainder;
+            cand = table[h];
+            table[h] = (uint16_t)s;
+            h = (rd32(src + next_s) * 0x1e35a7bdu) >> (32 - TBITS);
+            if (rd32(src + s) == rd32(src + cand)) break;
+        }
+        d += sn_emit_literal(dst + d, src + lit, s - lit);
+        for (;;) {
+            const size_t base = s;
+            s += 4;
+            size_t i = cand + 4;
+            while (s < n && src[i] == src[s]) { i++; s++; }
+            d += sn_emit_copy(dst + d, base - cand, s - base);
+            lit = s;
+            if (s >= slimit) goto remainder;
+            const uint64_t x = rd64(src + s - 1);
+            const uint32_t hp = ((uint32_t)x * 0x1e35a7bdu) >> (32 - TBITS);
+            table[hp] = (uint16_t)(s - 1);
+            const uint32_t hc = ((uint32_t)(x >> 8) * 0x1e35a7bdu) >> (32 - TBITS);
+            cand = table[hc];
+            table[hc] = (uint16_t)s;
+            if ((uint32_t)(x >> 8) != rd32(src + cand)) { h = ((uint32_t)(x >> 16) * 0x1e35a7bdu) >> (32 - TBITS); s++; break; }
+        }
+    }
+remainder:
+    if (lit < n) d += sn_emit_literal(dst + d, src + lit, n - lit);
+    return d;
+}
+/* snappy.Encode(nil, src): uvarint(len) + the blocks' elements */
+int64_t ob_snappy_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap) {
+    if (cap < ob_snappy_bound(n)) return OB_ERR_SHORT_BUFFER;
+    size_t d = sn_put_uvarint(dst, n);
+    for (size_t off = 0; off < n; off += 65536) {
+        const size_t len = n - off < 65536 ? n - off : 65536;
+        d += sn_encode_block(dst + d, src + off, len);
+    }
+    return (int64_t)d;
+}
+/* snappy.Decode(buf[:cap], src): *declared = the uvarint length; returns the decoded byte count (== *declared) or an error.
+ * A declared length above cap cannot be decoded into the caller's buffer: OB_ERR_SHORT_BUFFER (the frame layer reports it as
+ * ErrSizeMismatch: the reference would decode into its own buffer and then fail the NBytesOrig comparison, blosc.go:429-431). */
+int64_t ob_snappy_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, uint64_t *declared) {
+    uint64_t dlen = 0; size_t s = 0; int okv = 0;
+    for (unsigned i = 0; i < 10 && i < n; i++) {
+        const unsigned b = src[i];
+        dlen |= (uint64_t)(b & 127) << (7 * i);
+        if (!(b & 128)) { s = i + 1; okv = !(i == 9 && b > 1); break; }
+    }
+    if (!okv || dlen > 0xFFFFFFFFull) return OB_ERR_DECOMPRESSION_FAILED;
+    if (declared) *declared = dlen;
+    if (dlen > cap) return OB_ERR_SHORT_BUFFER;
+    size_t d = 0;
+    while (s < n) {
+        const unsigned t = src[s];
+        size_t length, offset;
+        if ((t & 3) == 0) {
+            size_t x = t >> 2;
+            if (x < 60) s += 1;
+            else {
+                const size_t nb = x - 59;
+                if (n - s < 1 + nb) return OB_ERR_DECOMPRESSION_FAILED;
+                x = 0;
+                for (size_t i = 0; i < nb; i++) x |= (size_t)src[s + 1 + i] << (8 * i);
+                s += 1 + nb;
+            }
+            length = x + 1;
+            if (length > dlen - d || length > n - s) return OB_ERR_DECOMPRESSION_FAILED;
+            memcpy(dst + d, src + s, length);
+            d += length; s += length;
+            continue;
+        }
+        if ((t & 3) == 1) { if (n - s < 2) return OB_ERR_DECOMPRESSION_FAILED; length = 4 + ((t >> 2) & 7); offset = ((size_t)(t & 0xe0) << 3) | src[s + 1]; s += 2; }
+        else if ((t & 3) == 2) { if (n - s < 3) return OB_ERR_DECOMPRESSION_FAILED; length = 1 + (t >> 2); offset = src[s + 1] | ((size_t)src[s + 2] << 8); s += 3; }
+        else { if (n - s < 5) return OB_ERR_DECOMPRESSION_FAILED; length = 1 + (t >> 2);
+               offset = src[s + 1] | ((size_t)src[s + 2] << 8) | ((size_t)src[s + 3] << 16) | ((size_t)src[s + 4] << 24); s += 5; }
+        if (offset == 0 || d < offset || length > dlen - d) return OB_ERR_DECOMPRESSION_FAILED;
+        for (size_t k = 0; k < length; k++) dst[d + k] = dst[d - offset + k];
+        d += length;
+    }
+    if (d != dlen) return OB_ERR_DECOMPRESSION_FAILED;
+    return (int64_t)d;
+}
+
+/* ------------------------------------------------------------------------- */
 /* frame layer                                                               */
 /* ------------------------------------------------------------------------- */
 
@@ -275,10 +407,10 @@ void ob_header_bytes(const ob_header *h, uint8_t out[16]) {
     put32(out + 4, h->nbytes); put32(out + 8, h->blocksize); put32(out + 12, h->cbytes);
 }
 
-size_t ob_frame_bound(size_t n) { return OB_HEADER_SIZE + ob_lz4_bound(n); }
+size_t ob_frame_bound(size_t n) { return OB_HEADER_SIZE + (ob_snappy_bound(n) > ob_lz4_bound(n) ? ob_snappy_bound(n) : ob_lz4_bound(n)); }
 
-static int codec_known(int codec) {       /* the registry of codec.go:27-33; only LZ4-family restated */
-    return codec == OB_LZ4 || codec == OB_LZ4HC;
+static int codec_known(int codec) {       /* the registry of codec.go:27-33; LZ4 family and Snappy restated */
+    return codec == OB_LZ4 || codec == OB_LZ4HC || codec == OB_SNAPPY;
 }
 
 /* CompressWithOptions + compressBackend, blosc.go:268-374.
@@ -291,8 +423,9 @@ int64_t ob_compress_frame(const uint8_t *src, size_t n, uint8_t *dst, size_t cap
     if (level < 1) level = 1;                                    /* :277-279 */
     if (level > 9) level = 9;                                    /* :280-282 */
     (void)level;                                                 /* LZ4 ignores it, codec.go:63-66 */
-    if (codec != OB_LZ4) return OB_ERR_INVALID_CODEC;            /* :322-325 */
-    if (n > 0xFFFFFFFFu - OB_HEADER_SIZE - n / 255 - 16) return OB_ERR_DATA_TOO_LARGE; /* Appendix D */
+    /* LZ4HC (codec.go:94-118): any valid LZ4 block is a valid payload; the greedy encoder stands in for CompressBlockHC */
+    if (codec != OB_LZ4 && codec != OB_LZ4HC && codec != OB_SNAPPY) return OB_ERR_INVALID_CODEC;   /* :322-325 */
+    if (n > 0xFFFFFFFFu - OB_HEADER_SIZE - n / 6 - 64) return OB_ERR_DATA_TOO_LARGE; /* Appendix D */
     if (cap < ob_frame_bound(n)) return OB_ERR_SHORT_BUFFER;
 
     uint8_t *filtered = NULL;
@@ -304,7 +437,8 @@ int64_t ob_compress_frame(const uint8_t *src, size_t n, uint8_t *dst, size_t cap
         else ob_bitshuffle(filtered, src, n, typesize);
         in = filtered;
     }
-    int64_t c = ob_lz4_compress(in, n, dst + OB_HEADER_SIZE, cap - OB_HEADER_SIZE);   /* :336 */
+    int64_t c = codec == OB_SNAPPY ? ob_snappy_compress(in, n, dst + OB_HEADER_SIZE, cap - OB_HEADER_SIZE)    /* :336 -> codec.go:232-235 */
+                                   : ob_lz4_compress(in, n, dst + OB_HEADER_SIZE, cap - OB_HEADER_SIZE);       /* :336 -> codec.go:63-75 */
     if (c < 0) { free(filtered); return OB_ERR_COMPRESSION_FAILED; }
     const int use_memcpy = (size_t)c >= n;                       /* :342 */
     if (use_memcpy) {
@@ -345,7 +479,10 @@ int64_t ob_decompress_frame(const uint8_t *f, size_t n, uint8_t *dst, size_t cap
         memcpy(tmp, payload, plen); got = (int64_t)plen;
     } else {
         if (!codec_known(h.codec)) { free(tmp); return OB_ERR_INVALID_CODEC; }   /* :403-407 */
-        got = ob_lz4_decompress(payload, plen, tmp, h.nbytes);   /* :410 -> codec.go:77-84 */
+        if (h.codec == OB_SNAPPY) {                              /* :410 -> codec.go:237-244 */
+            got = ob_snappy_decompress(payload, plen, tmp, h.nbytes, NULL);
+            if (got == OB_ERR_SHORT_BUFFER) { free(tmp); return OB_ERR_SIZE_MISMATCH; }   /* declared > NBytesOrig, see ob_snappy_decompress */
+        } else got = ob_lz4_decompress(payload, plen, tmp, h.nbytes);   /* :410 -> codec.go:77-84 */
         if (got < 0) { free(tmp); return OB_ERR_DECOMPRESSION_FAILED; }           /* :411-413 */
     }
     int ts = ts_override > 0 ? ts_override : (int)h.typesize;    /* :417-419 */

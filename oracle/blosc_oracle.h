@@ -72,6 +72,9 @@ void ob_filter(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize)
 size_t  ob_lz4_bound(size_t n);                                                     /* codec.go:65 */
 int64_t ob_lz4_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap);    /* codec.go:66 */
 int64_t ob_lz4_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap);  /* codec.go:79 */
+size_t  ob_snappy_bound(size_t n);                                                   /* snappy.MaxEncodedLen */
+int64_t ob_snappy_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap);  /* codec.go:234 */
+int64_t ob_snappy_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, uint64_t *declared);   /* codec.go:239 */
 
 /* ---- frame layer (blosc.go) ---- */
 int     ob_parse_header(const uint8_t *frame, size_t n, ob_header *h);              /* blosc.go:165-185 */

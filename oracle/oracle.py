@@ -21,7 +21,7 @@ ERR = {
     -5: "SIZE_MISMATCH", -6: "DATA_TOO_LARGE", -7: "COMPRESSION_FAILED",
     -8: "DECOMPRESSION_FAILED", -12: "SHORT_BUFFER",
 }
-LZ4, LZ4HC = 1, 2
+LZ4, LZ4HC, SNAPPY = 1, 2, 3
 NOSHUFFLE, SHUFFLE, BITSHUFFLE = 0, 1, 2
 OP_SHUFFLE, OP_UNSHUFFLE, OP_BITSHUFFLE, OP_BITUNSHUFFLE = 0, 1, 2, 3
 POLICY_REFERENCE_MEMCPY = 1
@@ -50,6 +50,9 @@ def lib():
         L.ob_lz4_bound.argtypes = [sz]; L.ob_lz4_bound.restype = sz
         L.ob_lz4_compress.argtypes = [u8p, sz, u8p, sz]; L.ob_lz4_compress.restype = i64
         L.ob_lz4_decompress.argtypes = [u8p, sz, u8p, sz]; L.ob_lz4_decompress.restype = i64
+        L.ob_snappy_bound.argtypes = [sz]; L.ob_snappy_bound.restype = sz
+        L.ob_snappy_compress.argtypes = [u8p, sz, u8p, sz]; L.ob_snappy_compress.restype = i64
+        L.ob_snappy_decompress.argtypes = [u8p, sz, u8p, sz, ctypes.POINTER(ctypes.c_uint64)]; L.ob_snappy_decompress.restype = i64
         L.ob_frame_bound.argtypes = [sz]; L.ob_frame_bound.restype = sz
         L.ob_compress_frame.argtypes = [u8p, sz, u8p, sz] + [ctypes.c_int] * 4 + [ctypes.c_uint]
         L.ob_compress_frame.restype = i64
@@ -101,6 +104,26 @@ def lz4_decompress(src, cap):
     s = _u8(src)
     d = np.empty(max(cap, 1), dtype=np.uint8)
     r = lib().ob_lz4_decompress(_ptr(s), s.size, _ptr(d), cap)
+    if r < 0:
+        raise OracleError(r)
+    return d[:r].copy()
+
+
+def snappy_compress(src):
+    s = _u8(src)
+    d = np.empty(lib().ob_snappy_bound(s.size), dtype=np.uint8)
+    c = lib().ob_snappy_compress(_ptr(s), s.size, _ptr(d), d.size)
+    if c < 0:
+        raise OracleError(c)
+    return d[:c].copy()
+
+
+def snappy_decompress(src, cap):
+    """Returns the decoded bytes (the declared length); raises OracleError on malformed input or when the declared length
+    exceeds cap (-12)."""
+    s = _u8(src)
+    d = np.empty(max(cap, 1), dtype=np.uint8)
+    r = lib().ob_snappy_decompress(_ptr(s), s.size, _ptr(d), cap, None)
     if r < 0:
         raise OracleError(r)
     return d[:r].copy()

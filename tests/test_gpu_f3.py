@@ -1,0 +1,237 @@
+"""GPU parity for SURVEY §8 row f3: LZ4HC (codec.go:90-128) and Snappy (codec.go:228-244) on the device, and Options.Level as
+a speed knob for LZ4 (codec.go:63-66 ignores it; any level must still give a valid block).
+
+Checkers: the oracle's decoders (restated reference `Decompress`), liblz4 for the LZ4 block behind codec id 2, libsnappy (the
+format's own library) for codec id 3.  The reference pins no compressed bytes for these codecs either (third-party encoders
+that are not in its tree): what is pinned is decodability by the reference's decoders + its error identities.
+"""
+import ctypes
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _liblz4():
+    for p in ("/usr/lib/x86_64-linux-gnu/liblz4.so.1", "/opt/conda/lib/liblz4.so.1"):
+        if os.path.exists(p):
+            return ctypes.CDLL(p)
+    return None
+
+
+def _libsnappy():
+    p = "/opt/conda/lib/libsnappy.so.1"
+    if not os.path.exists(p):
+        return None
+    lib = ctypes.CDLL(p)
+    lib.snappy_uncompress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.snappy_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.snappy_max_compressed_length.argtypes = [ctypes.c_size_t]; lib.snappy_max_compressed_length.restype = ctypes.c_size_t
+    return lib
+
+
+def _cases(O):
+    rng = np.random.default_rng(12)
+    return {
+        "f32_1MiB": O.synth(O.D_F32, 1 << 18), "f64": O.synth(O.D_F64, 70000), "i32": O.synth(O.D_I32, 1 << 16),
+        "ramp": O.synth(O.D_RAMP, 50000), "mod256": (np.arange(100000) % 256).astype(np.uint8),     # blosc_test.go:363-371
+        "zeros": np.zeros(10000, np.uint8), "random": rng.integers(0, 256, 50001, dtype=np.uint8),
+        "run_70000": np.full(70000, 9, np.uint8), "tiny_1": np.array([7], np.uint8), "tiny_13": np.arange(13, dtype=np.uint8),
+        "period100": np.tile(rng.integers(0, 256, 100, dtype=np.uint8), 700),
+        "few_valued": (rng.integers(0, 4, 1 << 18, dtype=np.uint8) * 64),
+        "ragged_multi_tile": O.synth(O.D_F32, (3 << 20) // 4 + 5).view(np.uint8)[: (3 << 20) + 17].copy(),
+    }
+
+
+MODES = [(0, 1), (1, 4), (2, 4), (1, 8), (1, 2), (1, 3)]
+
+
+def test_lz4hc_frames_every_level(hb, O):
+    # blosc_test.go:91-105 (LZ4HC round trip) + codec.go:96-106 (level map): every level gives codec id 2 and an LZ4 block that
+    # the reference's decoder (oracle), liblz4 and the device decode to the input; deeper levels never compress worse on the
+    # structured sets
+    lz = _liblz4()
+    for name, x in _cases(O).items():
+        xb = x.tobytes()
+        sizes = {}
+        for level in (1, 5, 7, 9):
+            for shuffle, ts in (MODES if level == 5 else MODES[:2]):
+                f = hb.Compress(xb, hb.LZ4HC, level, shuffle, ts, opts=hb.OPT_INDEX_TRAILER)
+                h = hb.ParseHeader(f)
+                assert h.VersionLZ == hb.LZ4HC and h.NBytesOrig == len(xb)
+                assert O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes() == xb, (name, level, shuffle, ts)
+                assert hb.Decompress(f) == xb, (name, level, shuffle, ts)
+                if not h.IsMemcpy():
+                    assert hb.lib().hb_last_result_flags() & 1, (name, level)
+                    if lz is not None:
+                        out = ctypes.create_string_buffer(len(xb))
+                        filt = xb if (shuffle == 0 or ts <= 1) else O.filter({1: O.OP_SHUFFLE, 2: O.OP_BITSHUFFLE}[shuffle], x, ts).tobytes()
+                        assert lz.LZ4_decompress_safe(f[16:h.NBytesComp], out, h.NBytesComp - 16, len(xb)) == len(xb) and out.raw == filt
+                if (shuffle, ts) == (1, 4):
+                    sizes[level] = h.NBytesComp
+        if name in ("f32_1MiB", "few_valued", "i32"):
+            assert sizes[9] <= sizes[7] <= sizes[5] <= sizes[1] * 1.001, (name, sizes)
+            lz4 = hb.ParseHeader(hb.Compress(xb, hb.LZ4, 5, 1, 4)).NBytesComp
+            assert sizes[9] <= lz4, (name, sizes, lz4)
+            if name != "i32":                                               # (two random + two zero byte planes: nothing to find)
+                assert sizes[9] < lz4, (name, sizes, lz4)                   # the deeper search must buy something
+
+
+def test_lz4_level_is_a_speed_knob_only(hb, O):
+    # codec.go:63-66: lz4Codec ignores the level; here it only changes how hard the matcher skips -- validity never
+    for name, x in _cases(O).items():
+        xb = x.tobytes()
+        got = {}
+        for level in (-5, 1, 3, 5, 7, 9, 100):                              # blosc_test.go:613-655: out-of-range levels are clamped
+            f = hb.Compress(xb, hb.LZ4, level, hb.Shuffle1, 4, opts=hb.OPT_INDEX_TRAILER)
+            assert hb.Decompress(f) == xb and O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes() == xb, (name, level)
+            got[level] = hb.ParseHeader(f).NBytesComp
+        assert got[-5] == got[1] and got[100] == got[9]
+        assert got[9] <= got[5] * 1.0005 and got[5] <= got[1] * 1.0005, (name, got)
+
+
+def test_snappy_frames(hb, O):
+    # blosc_test.go:69-89 (Snappy round trip): codec id 3; the payload is ONE Snappy block that the reference's decoder (oracle),
+    # libsnappy and the device decode to the filtered input
+    sn = _libsnappy()
+    for name, x in _cases(O).items():
+        xb = x.tobytes()
+        for shuffle, ts in MODES:
+            for opts in (hb.OPT_INDEX_TRAILER, 0):
+                f = hb.Compress(xb, hb.Snappy, 5, shuffle, ts, opts=opts)
+                h = hb.ParseHeader(f)
+                assert (h.Version, h.VersionLZ, h.TypeSize, h.NBytesOrig) == (2, hb.Snappy, ts, len(xb))
+                assert O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes() == xb, (name, shuffle, ts)
+                assert hb.Decompress(f) == xb, (name, shuffle, ts, opts)
+                if not h.IsMemcpy():
+                    assert (hb.lib().hb_last_result_flags() & 1) == (1 if opts else 0), (name, shuffle, ts, opts)
+                    if sn is not None and opts:
+                        out = ctypes.create_string_buffer(len(xb))
+                        ol = ctypes.c_size_t(len(xb))
+                        assert sn.snappy_uncompress(f[16:h.NBytesComp], h.NBytesComp - 16, out, ctypes.byref(ol)) == 0 and ol.value == len(xb)
+                        filt = xb if (shuffle == 0 or ts <= 1) else O.filter({1: O.OP_SHUFFLE, 2: O.OP_BITSHUFFLE}[shuffle], x, ts).tobytes()
+                        assert out.raw == filt, (name, shuffle, ts)
+    with pytest.raises(hb.ErrInvalidData):
+        hb.Compress(b"", hb.Snappy, 5, hb.NoShuffle, 1)                     # blosc.go:269-271
+
+
+def test_device_decodes_foreign_snappy_frames(hb, O):
+    # frames whose payload was written by the oracle's encoder (64 KiB blocks, offsets up to 65535) and by libsnappy: no
+    # index -> the single-wavefront decoder; plus a hand-made block with a 4-byte-offset copy reaching 100 000 bytes back
+    sn = _libsnappy()
+    for name, x in _cases(O).items():
+        xb = x.tobytes()
+        for shuffle, ts in MODES[:3]:
+            f = O.compress_frame(x, codec=O.SNAPPY, shuffle=shuffle, typesize=ts).tobytes()
+            assert hb.Decompress(f) == xb, (name, shuffle, ts)
+            assert not (hb.lib().hb_last_result_flags() & 1)
+        if sn is not None and len(xb) > 20:
+            cap = sn.snappy_max_compressed_length(len(xb))
+            b = ctypes.create_string_buffer(cap)
+            bl = ctypes.c_size_t(cap)
+            assert sn.snappy_compress(xb, len(xb), b, ctypes.byref(bl)) == 0
+            if bl.value < len(xb):
+                frame = struct.pack("<BBBBIII", 2, hb.Snappy, 0, 1, len(xb), len(xb), 16 + bl.value) + b.raw[:bl.value]
+                assert hb.Decompress(frame) == xb, name
+    rng = np.random.default_rng(3)
+    head = rng.integers(0, 256, 120000, dtype=np.uint8).tobytes()
+    n = len(head) + 40
+
+    def lit(b):
+        x = len(b) - 1
+        return (bytes([x << 2]) if x < 60 else bytes([61 << 2, x & 255, x >> 8]) if x < 65536 else bytes([62 << 2, x & 255, (x >> 8) & 255, x >> 16])) + b
+    block = bytes([n & 127 | 128, (n >> 7) & 127 | 128, n >> 14]) + lit(head) + bytes([(40 - 1) << 2 | 3]) + struct.pack("<I", 100000)
+    want = head + head[len(head) - 100000:][:40]
+    assert O.snappy_decompress(np.frombuffer(block, np.uint8), n).tobytes() == want
+    frame = struct.pack("<BBBBIII", 2, hb.Snappy, 0, 1, n, n, 16 + len(block)) + block
+    assert hb.Decompress(frame) == want
+
+
+def test_snappy_errors_match_the_oracle(hb, O):
+    # mutated Snappy frames: the device must report what the restated reference decoder reports (error class, or the same bytes)
+    rng = np.random.default_rng(99)
+    by_code = {-1: hb.ErrInvalidData, -2: hb.ErrInvalidHeader, -3: hb.ErrInvalidVersion, -4: hb.ErrInvalidCodec,
+               -5: hb.ErrSizeMismatch, -8: hb.ErrDecompressionFailed}
+    x = O.synth(O.D_F32, 6000).tobytes()
+    seeds = [hb.Compress(x, hb.Snappy, 5, 1, 4, opts=hb.OPT_INDEX_TRAILER), hb.Compress(x, hb.Snappy, 5, 0, 1),
+             O.compress_frame(np.frombuffer(x, np.uint8), codec=O.SNAPPY, shuffle=2, typesize=4).tobytes()]
+    checked = 0
+    for f in seeds:
+        cb = hb.ParseHeader(f).NBytesComp
+        for trial in range(120):
+            g = bytearray(f)
+            kind = trial % 4
+            if kind == 0:
+                g[int(rng.integers(16, cb))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                pos = int(rng.integers(16, cb))
+                g[pos:pos + 4] = rng.integers(0, 256, min(4, len(g) - pos), dtype=np.uint8).tobytes()
+            elif kind == 2:
+                cut = int(rng.integers(17, cb))
+                g = g[:cut]; g[12:16] = struct.pack("<I", cut)
+            else:
+                g[4:8] = struct.pack("<I", max(1, int.from_bytes(g[4:8], "little") + int(rng.integers(-50, 50))))
+            g = bytes(g)
+            try:
+                want = (None, O.decompress_frame(np.frombuffer(g, np.uint8)).tobytes())
+            except O.OracleError as e:
+                want = (by_code[e.code], None)
+            try:
+                got = (None, hb.Decompress(g))
+            except hb.BloscError as e:
+                got = (type(e), None)
+            assert got == want, (trial, kind, got[0], want[0])
+            checked += 1
+    assert checked == 360
+
+
+def test_snappy_forged_index_is_not_trusted(hb, O):
+    # a checksum-correct HBSX index with the wrong unit geometry, or with offsets that do not sit on element boundaries, must
+    # not change the decoded bytes
+    x = O.synth(O.D_F32, 8192).tobytes()
+    f = hb.Compress(x, hb.Snappy, 5, hb.Shuffle1, 4, opts=hb.OPT_INDEX_TRAILER)
+    h = hb.ParseHeader(f)
+    ioff = (h.NBytesComp + 7) & ~7
+    idx = bytearray(f[ioff:])
+    w = list(struct.unpack("<8I", idx[:32]))
+    assert w[0] == 0x58534248 and w[2] == 8
+    assert hb.Decompress(f) == x and hb.lib().hb_last_result_flags() & 1
+    for edit in ("half_units", "shift_entry", "swap"):
+        g = bytearray(idx)
+        ww = list(w)
+        ents = list(struct.unpack("<9I", g[32:32 + 36]))
+        if edit == "half_units":
+            ww[2] = 4; ww[3] = 8192; ents = ents[0:9:2]
+        elif edit == "shift_entry":
+            ents[3] += 1
+        else:
+            ents[2], ents[5] = ents[5], ents[2]
+        ww[7] = ww[0] ^ ww[1] ^ ww[2] ^ ww[3] ^ ww[4] ^ ww[5] ^ ww[6]
+        forged = f[:ioff] + struct.pack("<8I", *ww) + struct.pack(f"<{len(ents)}I", *ents)
+        assert hb.Decompress(forged) == x, edit
+        assert not (hb.lib().hb_last_result_flags() & 1), edit
+
+
+def test_f3_codecs_through_the_queue_and_at_full_size(hb, O):
+    L = hb.lib()
+    n = 64 << 20
+    x = O.synth(O.D_F32, n // 4, frame=2)
+    cap = L.hb_frame_bound(n)
+    pin_in, pin_out, back = hb.PinnedBuffer(n), hb.PinnedBuffer(cap), hb.PinnedBuffer(n)
+    ctypes.memmove(pin_in.ptr, x.ctypes.data, n)
+    q = hb.FrameQueue(n, depth=2)
+    ratios = {}
+    for codec, level in ((hb.Snappy, 5), (hb.LZ4HC, 9), (hb.LZ4HC, 5), (hb.LZ4, 5)):
+        c = q.wait(q.compress(pin_in.ptr, n, pin_out.ptr, cap, codec, level, hb.Shuffle1, 4, hb.OPT_INDEX_TRAILER))
+        frame = bytes(pin_out.view[:c])
+        h = hb.ParseHeader(frame)
+        assert h.VersionLZ == codec and not h.IsMemcpy()
+        assert np.array_equal(O.decompress_frame(np.frombuffer(frame[:h.NBytesComp], np.uint8)), x), (codec, level)
+        assert q.wait(q.decompress(pin_out.ptr, c, back.ptr, n)) == n
+        assert bytes(back.view[:n]) == x.tobytes(), (codec, level)
+        ratios[(codec, level)] = h.NBytesComp / n
+    q.close()
+    assert ratios[(hb.LZ4HC, 9)] < ratios[(hb.LZ4HC, 5)] < ratios[(hb.LZ4, 5)] < ratios[(hb.Snappy, 5)] + 0.2, ratios

@@ -252,3 +252,66 @@ def test_reference_compress_seeds_round_trip(O):
             f = O.compress_frame(x, shuffle=0, typesize=ts)
             assert np.array_equal(O.decompress_frame(f), x), (s["name"], ts)
             assert f[3] == (max(ts, 1) & 0xFF)                                      # uint8(opts.TypeSize) after the clamp, blosc.go:274-276, :362
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Snappy (codec.go:228-244): the restated block codec against the format's reference library (libsnappy)
+# ---------------------------------------------------------------------------------------------------------------
+def _libsnappy():
+    lib = _load("/opt/conda/lib/libsnappy.so.1")
+    if lib is None:
+        return None
+    lib.snappy_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.snappy_uncompress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
+    lib.snappy_max_compressed_length.argtypes = [ctypes.c_size_t]; lib.snappy_max_compressed_length.restype = ctypes.c_size_t
+    return lib
+
+
+def test_snappy_round_trips_and_libsnappy_agreement(O):
+    sn = _libsnappy()
+    for name, x in _datasets(O).items():
+        for filt in (None, (0, 4), (2, 4)):
+            s = x if filt is None else O.filter(filt[0], x, filt[1])
+            c = O.snappy_compress(s)
+            assert np.array_equal(O.snappy_decompress(c, s.size), s), name
+            if sn is not None:
+                out = ctypes.create_string_buffer(max(s.size, 1))
+                ol = ctypes.c_size_t(s.size)
+                assert sn.snappy_uncompress(c.tobytes(), c.size, out, ctypes.byref(ol)) == 0 and out.raw[:ol.value] == s.tobytes(), name
+                cap = sn.snappy_max_compressed_length(s.size)
+                b = ctypes.create_string_buffer(cap)
+                bl = ctypes.c_size_t(cap)
+                assert sn.snappy_compress(s.tobytes(), s.size, b, ctypes.byref(bl)) == 0
+                assert np.array_equal(O.snappy_decompress(np.frombuffer(b.raw[:bl.value], np.uint8), s.size), s), name
+
+
+def test_snappy_decoder_rejections_and_frames(O):
+    def rej(stream, cap=100):
+        with pytest.raises(O.OracleError) as e:
+            O.snappy_decompress(np.frombuffer(bytes.fromhex(stream), np.uint8), cap)
+        return e.value.code
+    assert O.snappy_decompress(np.frombuffer(bytes.fromhex("00"), np.uint8), 10).size == 0          # empty block
+    assert O.snappy_decompress(np.frombuffer(bytes.fromhex("03" "08" "616263"), np.uint8), 10).tobytes() == b"abc"
+    assert O.snappy_decompress(np.frombuffer(bytes.fromhex("08" "00" "61" "0d" "01"), np.uint8), 10).tobytes() == b"a" * 8   # literal a + copy (1-byte offset form): offset 1, len 7
+    assert rej("") == -8 and rej("ff") == -8                                   # no / truncated uvarint
+    assert rej("05" "08" "616263") == -8                                       # fewer bytes than declared
+    assert rej("02" "08" "616263") == -8                                       # more bytes than declared
+    assert rej("05" "00" "61" "01" "00") == -8                                 # copy with offset 0
+    assert rej("05" "00" "61" "01" "05") == -8                                 # offset beyond the bytes produced
+    assert rej("05" "08" "6162") == -8                                         # literal runs past the input
+    assert rej("e807" + "00" * 4, cap=100) == -12                              # declares 1000 bytes into a 100-byte buffer
+    x = (np.arange(5000) % 251).astype(np.uint8)
+    for shuffle, ts in [(0, 1), (1, 4), (2, 4), (1, 8)]:
+        f = O.compress_frame(x, codec=O.SNAPPY, shuffle=shuffle, typesize=ts)
+        assert f[1] == 3 and np.array_equal(O.decompress_frame(f), x)
+    f = O.compress_frame(x, codec=O.SNAPPY, shuffle=0, typesize=1)
+    b = f.copy(); b[4:8] = np.frombuffer(struct.pack("<I", 6000), np.uint8)    # NBytesOrig tampered up: decodes, then ErrSizeMismatch
+    with pytest.raises(O.OracleError) as e:
+        O.decompress_frame(b, cap=8000)
+    assert e.value.code == -5
+    b = f.copy(); b[4:8] = np.frombuffer(struct.pack("<I", 4000), np.uint8)    # tampered down: declared 5000 > 4000 -> ErrSizeMismatch
+    with pytest.raises(O.OracleError) as e:
+        O.decompress_frame(b)
+    assert e.value.code == -5
+    g = O.compress_frame(x, codec=O.LZ4HC, shuffle=1, typesize=4)              # codec id 2: an LZ4 block behind the LZ4HC id
+    assert g[1] == 2 and np.array_equal(O.decompress_frame(g), x)

@@ -3,7 +3,10 @@
  *   gcc -O2 -o gpu_lz4_model gpu_lz4_model.c && ./gpu_lz4_model <file> [chunk] [hlog] [flags]
  * flags: bit0 = probe offset 1, bit1 = probe offset `aux`, bit2 = backward extension, bit3 = skip acceleration,
  *        bit4 = positions whose 4 bytes equal those at p-1 (inside a run) are not inserted,
- *        bit5 = prefer the offset-1 candidate over the table candidate when both verify
+ *        bit5 = prefer the offset-1 candidate over the table candidate when both verify,
+ *        bit6 = a position whose table candidate verifies is NOT inserted (the table keeps the oldest verified occurrence: match
+ *               sources are then old data, which the decoder's dependency rounds like; prints the mean offset as a proxy),
+ *        bit7 = like bit6, but only when the candidate verifies for >= 12 bytes (the "keep_long" policy of k_match)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,7 +25,7 @@ int main(int argc, char **argv) {
     int chunk = argc > 2 ? atoi(argv[2]) : 4096, hlog = argc > 3 ? atoi(argv[3]) : 11, flags = argc > 4 ? atoi(argv[4]) : 0;
     int aux = argc > 5 ? atoi(argv[5]) : 4;
     uint16_t *tab = malloc(sizeof(uint16_t) << hlog);
-    uint64_t out = 0, nseq = 0, steps = 0; uint64_t carry = 0;
+    uint64_t out = 0, nseq = 0, steps = 0; uint64_t carry = 0; double offsum = 0; uint64_t near = 0;
     for (long start = 0; start < n; start += chunk) {
         const uint8_t *d = buf + start; int len = n - start < chunk ? (int)(n - start) : chunk;
         memset(tab, 0, sizeof(uint16_t) << hlog);
@@ -34,6 +37,8 @@ int main(int argc, char **argv) {
                 uint32_t v = rd4(d + p); uint32_t h = (v * 2654435761u) >> (32 - hlog); cand[l] = tab[h]; }
             for (int l = 0; l < 64; l++) { int p = pos + l; if (p > ms) continue; uint32_t v = rd4(d + p);
                 if ((flags & 16) && p >= 1 && rd4(d + p - 1) == v) continue;
+                if ((flags & 64) && cand[l] < p && rd4(d + cand[l]) == v) continue;
+                if ((flags & 128) && cand[l] < p && memcmp(d + cand[l], d + p, 12) == 0) continue;
                 tab[(v * 2654435761u) >> (32 - hlog)] = (uint16_t)p; }   /* highest lane wins */
             for (int l = 0; l < 64; l++) { int p = pos + l; if (p > ms) continue; uint32_t v = rd4(d + p);
                 int rle = (flags & 1) && p >= 1 && rd4(d + p - 1) == v;
@@ -49,7 +54,7 @@ int main(int argc, char **argv) {
                 if (ml < 4) continue;
                 uint32_t lit = mp - anchor;
                 if (first) { out += 1 + ext(lit + carry) + lit + carry; carry = 0; first = 0; } else out += 1 + ext(lit) + lit;
-                out += 2 + ext(ml - 4); nseq++;
+                out += 2 + ext(ml - 4); nseq++; offsum += mp - mc; if (mp - mc < 416) near++;
                 anchor = mp + ml; }
             if (any) miss = 0; else miss++;
             int nxt = pos + 64;
@@ -59,7 +64,7 @@ int main(int argc, char **argv) {
         carry += len - anchor;
     }
     out += 1 + ext(carry) + carry;
-    printf("n=%ld out=%llu ratio=%.4f seqs=%llu steps=%llu (%.2f steps/KiB)\n", n, (unsigned long long)out, (double)out / n,
-           (unsigned long long)nseq, (unsigned long long)steps, steps / (n / 1024.0));
+    printf("n=%ld out=%llu ratio=%.4f seqs=%llu steps=%llu (%.2f steps/KiB) mean offset %.0f, %.1f%% of matches reach < 416 B back\n", n, (unsigned long long)out, (double)out / n,
+           (unsigned long long)nseq, (unsigned long long)steps, steps / (n / 1024.0), nseq ? offsum / nseq : 0.0, nseq ? 100.0 * near / nseq : 0.0);
     return 0;
 }
