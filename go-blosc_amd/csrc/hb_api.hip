@@ -392,13 +392,20 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     uint8_t *dec_work = work + (((size_t)h.nbytes + 255) & ~(size_t)255) + 256;
     // bit-unshuffle with typesize 4 works inside 32-byte windows: fused into the indexed decoder when there are only
     // whole windows (the serial fallback still goes through `staged` + a gated un-filter pass, hb_lz4_dec.hip)
+    // restart index, if any, sits after cbytes (ignored by the reference decoder, blosc.go:385-393); without one there is nothing
+    // to fuse the un-filter into (the serial / region decoders produce the filtered bytes)
+    const size_t ioff = ((size_t)h.cbytes + 7) & ~(size_t)7;
+    // (a frame without the trailer gets its index rebuilt on the device when its payload is large enough, hb_lz4_region.hip; the
+    // fused un-filter is then armed the same way: if the rebuilt index does not hold, the serial path + the gated pass take over)
+    const bool has_index = !(h.flags & HB_FLAG_MEMCPY) && (n > ioff + 32 || ((size_t)h.cbytes - HB_HEADER_SIZE >= (256u << 10) && !snappy));
+    const bool stored_index = !(h.flags & HB_FLAG_MEMCPY) && n > ioff + 32;
     const bool fused_bun = unf == HB_OP_BITUNSHUFFLE && ts == 4 && (h.nbytes % 32u) == 0 && !(h.flags & HB_FLAG_MEMCPY) &&
-                           ((uintptr_t)d_dst & 15u) == 0 && !snappy;
+                           ((uintptr_t)d_dst & 15u) == 0 && !snappy && has_index;
     // byte un-shuffle: fused into the indexed decoder (byte-strided stores) when the frame is whole planes of whole chunks
     // (typesize 8: every 128-byte line would be completed by 8 different waves -- measured 0.2 ms per GiB SLOWER than the
     // separate pass, while typesize 2 and 4 win 0.2 ms)
     const bool fused_ush = unf == HB_OP_UNSHUFFLE && ts <= 4 && (h.nbytes % (uint32_t)ts) == 0 &&
-                           ((h.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && !(h.flags & HB_FLAG_MEMCPY) && !g_no_dec_fusion && !snappy;
+                           ((h.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && !(h.flags & HB_FLAG_MEMCPY) && !g_no_dec_fusion && !snappy && has_index;
     uint8_t *target = (unf >= 0 && !fused_bun && !fused_ush) ? staged : (uint8_t *)d_dst;
     const uint8_t *payload = (const uint8_t *)d_frame + HB_HEADER_SIZE;
     const size_t plen = h.cbytes - HB_HEADER_SIZE;
@@ -410,9 +417,7 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     a.fused_unshuffle_ts = fused_ush ? ts : 0;
     a.staged = staged;
     if (fused_bun || fused_ush) unf = -1;                             // nothing left to do after the decoder
-    // restart index, if any, sits after cbytes (ignored by the reference decoder, blosc.go:385-393)
-    const size_t ioff = ((size_t)h.cbytes + 7) & ~(size_t)7;
-    if (!a.memcpy_payload && n > ioff + 32) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }
+    if (stored_index) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }
     rc = snappy ? hb_launch_snappy_decode(a, s) : hb_launch_lz4_decode(a, s);
     if (rc) return rc;
     if (unf >= 0) {

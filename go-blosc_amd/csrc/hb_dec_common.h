@@ -4,6 +4,22 @@
 #pragma once
 #include "hb_lz4.h"
 
+struct DecPlan {
+    uint32_t mode;        // 0 = serial, 1 = indexed
+    uint32_t fail;        // set by any indexed unit that cannot vouch for its slice
+    uint32_t nunits;
+    uint32_t nbytes;      // decoded size the index declares
+    uint32_t post;        // set by k_dec_serial when it decoded into the staging buffer: the gated un-filter must run
+    uint32_t stride;      // unit order of the indexed decoder: u = i * stride mod nunits, gcd(stride, nunits) == 1
+    uint32_t pad[2];
+};
+enum { DEC_SERIAL = 0, DEC_INDEXED = 1 };
+
+// hb_lz4_region.hip: rebuilds the restart index of an LZ4 block that came without one (guess-and-verify token discovery)
+size_t hb_lz4_region_workspace(size_t n_out);
+bool hb_lz4_region_wanted(const hb_dec_args &a);
+int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size_t *index_bytes, hipStream_t s);
+
 #define DTQ 96                           // token queue slots: < 64 queued before a window is parsed; a 64-byte window adds <= 22 LZ4 tokens or <= 32 Snappy elements
 
 #define DLITCAP 16u
@@ -154,3 +170,113 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
     }
     return ok;
 }
+
+// ---- LZ4 token parsing shared by the indexed, serial and region decoders ----
+// Sum of an LZ4 length extension (bytes 255 ... 255 r) starting at slice offset si, read cooperatively 64 bytes
+// at a time; bytes beyond the staged window come straight from HBM (a literal run of many MiB has an
+// extension of tens of KiB).  Returns false when the extension runs off the slice or is absurdly long.
+__device__ __forceinline__ bool dec_read_ext(const uint8_t *in, int inoff, uint32_t wlo, uint32_t staged, const uint8_t *g, uint32_t slen,
+                                             uint32_t &si, uint32_t &acc, int lane) {
+    uint64_t sum = acc;
+    for (uint32_t round = 0;; round++) {
+        if (round == 1) {
+            // 64 bytes of 255 and counting: a literal run of MiB.  Scan 4 KiB per round trip with four 16-byte
+            // loads per lane in flight, straight from HBM/L2; the byte-granular loop below finishes the tail.
+            for (;;) {
+                bool allff = true;
+                u32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = si + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+                    if (i + 16u <= slen) v[k] = ld16u(g + i); else { v[k].x = 0; v[k].y = 0; v[k].z = 0; v[k].w = 0; }
+                }
+                uint32_t adv = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool ff = (v[k].x & v[k].y & v[k].z & v[k].w) == 0xFFFFFFFFu;
+                    const unsigned long long bad = hb_ballot(!ff);
+                    if (allff) {
+                        if (bad) { adv += 16u * (uint32_t)__builtin_ctzll(bad); allff = false; }
+                        else adv += 1024u;
+                    }
+                }
+                sum += 255ull * adv; si += adv;
+                if (sum > 0xFFFFFFF0ull) return false;
+                if (!allff) break;
+            }
+        }
+        const uint32_t i = si + lane;
+        uint32_t b = 0;                                   // out of range reads as a terminator
+        if (i < slen) b = (i >= wlo && i < staged) ? in[(uint32_t)((int)i + inoff)] : g[i];
+        const unsigned long long stop = hb_ballot(b != 255u);
+        if (stop == 0) { sum += 255u * 64u; si += 64; if (sum > 0xFFFFFFF0ull) return false; continue; }
+        const int f = __builtin_ctzll(stop);
+        if (si + (uint32_t)f >= slen) return false;
+        sum += 255u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane(b, f);
+        si += (uint32_t)f + 1;
+        if (sum > 0xFFFFFFF0ull) return false;
+        acc = (uint32_t)sum;
+        return true;
+    }
+}
+
+// FILL: parse windows of 64 stream bytes (in[k] = byte k of the slice, lim = bytes that may be looked at) until 64 tokens
+// are queued, the slice ends, or a token needs the one-at-a-time path (multi-byte length extension, too close to lim).
+// Returns true when it stopped for one of the latter reasons.  Tokens go to s_tq as {lsrc | lit << 13 | mlen << 22,
+// offset | tokpos << 16}, all slice-relative.
+__device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, const uint32_t slen,
+                                         uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si == slen) { stop = true; break; }
+        // every lane parses "as if a token started at my byte"
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t w = dec_read4(s_in, sh + p);
+        const uint32_t t = w & 255u;
+        uint32_t lit = t >> 4, nbl = 0;
+        bool cplx = p >= lim;
+        if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
+        const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
+        if (offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
+        const uint32_t x = dec_read4(s_in, sh + (cplx ? p : offpos));
+        const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
+        uint32_t mlen = 4u + mn, nbm = 0;
+        if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
+        const uint32_t nxt = offpos + 2u + nbm;
+        // follow the real token chain through the window: one bit-set + one readlane per token; a
+        // "complex" lane ends the walk (its successor is >= 64)
+        const unsigned long long cmask = hb_ballot(cplx);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const uint32_t nrel = cplx ? 64u : nxt - base;
+            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;   // the last token of the window points at itself
+            uint32_t j = 0, lastj;
+            for (;;) {                                       // unrolled by 4: setting the last bit again is harmless
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            const unsigned long long cm = tmask & cmask;  // at most the last visited lane
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        // queue the real tokens, compacted in stream order: {lsrc | lit << 13 | mlen << 22, offset | tokpos << 16}
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) {
+            uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
+            s_tq[nq + rank] = e;
+        }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+    }
+    return stop;
+}
+

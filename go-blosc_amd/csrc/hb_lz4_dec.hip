@@ -28,18 +28,7 @@
 #include "hb_lz4.h"
 #include "hb_dec_common.h"
 
-struct DecPlan {
-    uint32_t mode;        // 0 = serial, 1 = indexed
-    uint32_t fail;        // set by any indexed unit that cannot vouch for its slice
-    uint32_t nunits;
-    uint32_t nbytes;      // decoded size the index declares
-    uint32_t post;        // set by k_dec_serial when it decoded into the staging buffer: the gated un-filter must run
-    uint32_t stride;      // unit order of the indexed decoder: u = i * stride mod nunits, gcd(stride, nunits) == 1
-    uint32_t pad[2];
-};
-enum { DEC_SERIAL = 0, DEC_INDEXED = 1 };
-
-size_t hb_lz4_dec_workspace(size_t) { return 256; }
+size_t hb_lz4_dec_workspace(size_t n_out) { return 256 + hb_lz4_region_workspace(n_out); }
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return ld4u(p); }
 
@@ -75,114 +64,6 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
 #define DEC_IN_WIN  2560u                // bytes of a unit's stream slice that are staged in LDS at a time (the window moves)
 #define DEC_IN_MARGIN 320u               // a token closer than this to the end of the window is parsed after re-staging
 #define DEC_OUT_MAX HB_CHUNK             // largest output a unit may have
-
-// Sum of an LZ4 length extension (bytes 255 ... 255 r) starting at slice offset si, read cooperatively 64 bytes
-// at a time; bytes beyond the staged window come straight from HBM (a literal run of many MiB has an
-// extension of tens of KiB).  Returns false when the extension runs off the slice or is absurdly long.
-__device__ __forceinline__ bool dec_read_ext(const uint8_t *in, int inoff, uint32_t wlo, uint32_t staged, const uint8_t *g, uint32_t slen,
-                                             uint32_t &si, uint32_t &acc, int lane) {
-    uint64_t sum = acc;
-    for (uint32_t round = 0;; round++) {
-        if (round == 1) {
-            // 64 bytes of 255 and counting: a literal run of MiB.  Scan 4 KiB per round trip with four 16-byte
-            // loads per lane in flight, straight from HBM/L2; the byte-granular loop below finishes the tail.
-            for (;;) {
-                bool allff = true;
-                u32x4 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = si + (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-                    if (i + 16u <= slen) v[k] = ld16u(g + i); else { v[k].x = 0; v[k].y = 0; v[k].z = 0; v[k].w = 0; }
-                }
-                uint32_t adv = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool ff = (v[k].x & v[k].y & v[k].z & v[k].w) == 0xFFFFFFFFu;
-                    const unsigned long long bad = hb_ballot(!ff);
-                    if (allff) {
-                        if (bad) { adv += 16u * (uint32_t)__builtin_ctzll(bad); allff = false; }
-                        else adv += 1024u;
-                    }
-                }
-                sum += 255ull * adv; si += adv;
-                if (sum > 0xFFFFFFF0ull) return false;
-                if (!allff) break;
-            }
-        }
-        const uint32_t i = si + lane;
-        uint32_t b = 0;                                   // out of range reads as a terminator
-        if (i < slen) b = (i >= wlo && i < staged) ? in[(uint32_t)((int)i + inoff)] : g[i];
-        const unsigned long long stop = hb_ballot(b != 255u);
-        if (stop == 0) { sum += 255u * 64u; si += 64; if (sum > 0xFFFFFFF0ull) return false; continue; }
-        const int f = __builtin_ctzll(stop);
-        if (si + (uint32_t)f >= slen) return false;
-        sum += 255u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane(b, f);
-        si += (uint32_t)f + 1;
-        if (sum > 0xFFFFFFF0ull) return false;
-        acc = (uint32_t)sum;
-        return true;
-    }
-}
-
-// FILL: parse windows of 64 stream bytes (in[k] = byte k of the slice, lim = bytes that may be looked at) until 64 tokens
-// are queued, the slice ends, or a token needs the one-at-a-time path (multi-byte length extension, too close to lim).
-// Returns true when it stopped for one of the latter reasons.  Tokens go to s_tq as {lsrc | lit << 13 | mlen << 22,
-// offset | tokpos << 16}, all slice-relative.
-__device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, const uint32_t slen,
-                                         uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
-    bool stop = false;
-    while (nq < 64u && !stop) {
-        if (si == slen) { stop = true; break; }
-        // every lane parses "as if a token started at my byte"
-        const uint32_t base = si, p = base + (uint32_t)lane;
-        const uint32_t w = dec_read4(s_in, sh + p);
-        const uint32_t t = w & 255u;
-        uint32_t lit = t >> 4, nbl = 0;
-        bool cplx = p >= lim;
-        if (lit == 15u) { const uint32_t b1 = (w >> 8) & 255u; if (b1 == 255u) cplx = true; else { lit = 15u + b1; nbl = 1; } }
-        const uint32_t lsrc = p + 1u + nbl, offpos = lsrc + lit;
-        if (offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
-        const uint32_t x = dec_read4(s_in, sh + (cplx ? p : offpos));
-        const uint32_t offv = x & 0xFFFFu, mb = (x >> 16) & 255u, mn = t & 15u;
-        uint32_t mlen = 4u + mn, nbm = 0;
-        if (mn == 15u) { if (mb == 255u) cplx = true; else { mlen = 19u + mb; nbm = 1; } }
-        const uint32_t nxt = offpos + 2u + nbm;
-        // follow the real token chain through the window: one bit-set + one readlane per token; a
-        // "complex" lane ends the walk (its successor is >= 64)
-        const unsigned long long cmask = hb_ballot(cplx);
-        unsigned long long tmask = 0;
-        uint32_t cur;
-        {
-            const uint32_t nrel = cplx ? 64u : nxt - base;
-            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;   // the last token of the window points at itself
-            uint32_t j = 0, lastj;
-            for (;;) {                                       // unrolled by 4: setting the last bit again is harmless
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
-                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
-                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
-                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
-                j = __builtin_amdgcn_readlane(succ, (int)j3);
-                lastj = j3;
-                if (j == j3) break;
-            }
-            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
-            const unsigned long long cm = tmask & cmask;  // at most the last visited lane
-            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
-        }
-        // queue the real tokens, compacted in stream order: {lsrc | lit << 13 | mlen << 22, offset | tokpos << 16}
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-        if ((tmask >> lane) & 1ull) {
-            uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
-            s_tq[nq + rank] = e;
-        }
-        nq += (uint32_t)__builtin_popcountll(tmask);
-        si = cur;
-    }
-    return stop;
-}
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
@@ -603,11 +484,19 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
         return HB_OK;
     }
     DecPlan *plan = (DecPlan *)a.work;
+    const uint8_t *index = a.index;
+    size_t index_bytes = a.index_bytes;
+    // no index at all (a frame written without the trailer): rebuild it from the stream (hb_lz4_region.hip); what comes out is
+    // checked like a stored index, and a block that was not written chunk-locally simply ends up with the single wavefront
+    if (hb_lz4_region_wanted(a)) {
+        const int rc = hb_launch_lz4_region_index(a, &index, &index_bytes, s);
+        if (rc) return rc;
+    }
     hb_prof_begin("k_dec_plan", s);
-    hipLaunchKernelGGL(k_dec_plan, dim3(1), dim3(1), 0, s, a.index, (uint64_t)a.index_bytes, (uint64_t)a.n,
+    hipLaunchKernelGGL(k_dec_plan, dim3(1), dim3(1), 0, s, index, (uint64_t)index_bytes, (uint64_t)a.n,
                        (uint64_t)a.cap, plan, a.result);
     hb_prof_end(s);
-    if (a.index) {
+    if (index) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
         // a few units per workgroup (measured on 1 GiB: 16384 workgroups 1.84 ms, 65536 1.70 ms, 131072 2.09 ms, one unit per
         // workgroup 3.56 ms); odd when capped, so that the scrambled order rotates the mix of planes from pass to pass
@@ -622,7 +511,7 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
             if (g2) grid = g2;
         }
         hb_prof_begin("k_dec_indexed", s);
-        hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, a.index, plan,
+        hipLaunchKernelGGL(k_dec_indexed, dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, index, plan,
                            a.fused_bitunshuffle4, a.fused_unshuffle_ts, hb_dbg_plane_mask());
         hb_prof_end(s);
     }

@@ -39,6 +39,7 @@
 // Algorithmic HBM bytes: n (read) + C (write).  Extra traffic: records (~C written + read) and the literal
 // bytes of the source read a second time by k_stitch; see DESIGN.md.
 #include "hb_lz4.h"
+#include <cstdlib>
 
 #define HLOG 8
 #define HSIZE (1u << HLOG)

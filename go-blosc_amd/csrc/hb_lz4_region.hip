@@ -1,0 +1,655 @@
+// hb_lz4_region.hip — rebuilds the restart index of an LZ4 block that comes WITHOUT one (a frame written without
+// HB_OPT_INDEX_TRAILER -- the drop-in default, since the reference's frames end at NBytesComp; blosc.go:369-371), so that it decodes
+// chunk-parallel instead of on one wavefront.  Input contract: that of lz4.UncompressBlock (codec.go:77-84), nothing more.
+//
+// Two things make such a block serial: (1) nothing says where its sequences start -- token k+1 begins where token k ends;
+// (2) a match may copy from up to 65535 bytes back, i.e. from output that some other part of the stream produces.
+// Both are resolved by GUESSING in parallel and then VERIFYING exactly; wrong guesses are repaired by iteration, and anything
+// that does not check out leaves the block to the single-wavefront decoder (k_dec_serial), so the result never depends on luck.
+//
+//   (1) Sequence boundaries.  The stream is cut into R regions at fixed byte positions b_r.  k_rg_parse: one wavefront per
+//       region parses (window-parallel token parser of hb_dec_common.h, no copies) from b_r AS IF a token started there, to
+//       the first token at or after b_{r+1}; it keeps that exit, the output length, and a trace {position, output so far} of
+//       its first 256 tokens.  A parse started at a wrong byte is garbage, but LZ4 parses synchronise: after a few tokens the
+//       garbage parse usually falls onto a real token boundary and stays on the real chain.  k_rg_fix then walks the chain of
+//       beliefs "my first token = my predecessor's exit": region 0 is exact (a block starts with a token); a region whose
+//       belief changed re-parses from the new entry ONE token at a time until it lands on a position of its trace (the parses
+//       have merged: exit unchanged, output length corrected by the difference) -- or is re-parsed in full.  A few rounds, then
+//       k_rg_scan checks the whole chain (entry[r] == exit[r-1] for every r, last exit == end of block): a chain that passes is
+//       the true token chain, however it was found.  The prefix sum of the output lengths gives every region its place.
+//   (2) Match sources.  An arbitrary block cannot be decoded in pieces: in a stream with few literals and a 64 KiB window (what a
+//       CPU encoder writes on compressible data) every byte hangs on a long chain of earlier matches, and a decoder that starts
+//       somewhere in the middle with a wrong history never recovers (measured with a round-based re-decode of regions: on the
+//       reference-shaped D-f32 stream correctness advanced about two regions per round -- DESIGN.md).  What CAN be decoded in pieces
+//       is a block whose matches never leave their 4 KiB chunk of output: every block THIS library writes, with or without the
+//       index trailer.  So the second half rebuilds that trailer: k_rg_index walks the verified chain once more, now with output
+//       positions, and writes the HBIX entry of every 4 KiB unit -- or gives up at the first unit boundary that falls inside a
+//       match.  The rebuilt index then goes through k_dec_plan / k_dec_indexed like a stored one, which trust neither.
+//
+// Everything malformed (offset 0, offset before the block, lengths running off the stream, output beyond cap) only raises
+// plan->fail; k_dec_serial then decodes the block and reports what lz4.UncompressBlock would report.
+#include "hb_lz4.h"
+#include "hb_dec_common.h"
+
+#define RG_TRACE    256u          // trace entries per region: RG_DENSE first tokens + one per bucket of the region's stream range
+#define RG_DENSE    128u
+#define RG_BUCKETS  128u
+#define RG_INVALID  0xFFFFFFFFu
+#define RG_MAXREG   4096u
+#define RG_MINREG   65536u        // smallest region, stream bytes
+#define RG_PWIN     8192u         // parse window
+#define RG_FIXROUNDS 4             // k_rg_settle launches (each iterates to a standstill), full parses in between
+
+struct __attribute__((aligned(16))) RgRegion {
+    uint32_t b;          // nominal start (stream position)
+    uint32_t entry;      // belief: first token of this region (>= b of the next region: the region is empty)
+    uint32_t exit;       // first token at / after the next region's b when parsing from `entry`; RG_INVALID: parse failed
+    uint32_t outlen;     // output bytes of the tokens in [entry, exit)
+    uint32_t entry0, exit0, outlen0, ntrace;   // the parse the trace belongs to
+    uint32_t needfull;   // full parse from `entry` pending
+    uint32_t pad0;
+    uint64_t opos;       // output position of `entry`
+    uint32_t pad1[4];
+};
+struct RgPlan { uint32_t ok, fail, nreg, rs; uint64_t total; uint32_t pad[10]; };
+
+struct RgLayout { size_t plan, reg, pmax, trace, total; };
+static inline RgLayout rg_layout() {
+    RgLayout L; size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
+    L.plan = take(sizeof(RgPlan));
+    L.reg = take((size_t)RG_MAXREG * sizeof(RgRegion));
+    L.pmax = take((size_t)RG_MAXREG * 4);
+    L.trace = take((size_t)RG_MAXREG * RG_TRACE * sizeof(uint2));
+    L.total = o;
+    return L;
+}
+size_t hb_lz4_region_workspace(size_t n_out) { return rg_layout().total + ((hb_lz4_index_bound(n_out) + 255) & ~(size_t)255); }
+// blocks below 256 KiB stay with the single wavefront (a dozen launches cost more than they save)
+bool hb_lz4_region_wanted(const hb_dec_args &a) { return !a.index && !a.memcpy_payload && a.n >= (256u << 10) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull; }
+
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+
+// Window-parallel token parser for the passes that copy nothing.  Like dec_fill (hb_dec_common.h), but every lane also sums
+// multi-byte length extensions itself (up to 24 bytes each, i.e. lengths up to 6 KiB): a stream made of long runs (20-byte
+// sequences, each with a 16-byte match extension) would otherwise go through the one-token path sequence by sequence.
+// Queue entry: { tokpos | nbl << 16, lit | mlen << 16 }, positions relative to the window; literal bytes start at tokpos + 1 + nbl.
+__device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si == lim) { stop = true; break; }
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t t = p < lim ? (uint32_t)s_in[sh + p] : 0u;
+        bool cplx = p >= lim;
+        uint32_t lit = t >> 4, q = p + 1u;
+        // a length extension, four bytes per step (a lane that sits inside a run of 0xFF -- every byte of a long extension looks like
+        // the start of another one -- gives up after 24 bytes instead of crawling through it)
+        auto ext = [&](uint32_t &len, uint32_t &at) __attribute__((always_inline)) {
+            bool open = true;
+            for (int k = 0; k < 6 && open; k++) {
+                if (at + 4u > lim) break;
+                const uint32_t w = dec_read4(s_in, sh + at);
+                if (w == 0xFFFFFFFFu) { len += 1020u; at += 4u; }
+                else {
+                    const uint32_t nff = (uint32_t)__builtin_ctz(~w) >> 3;
+                    len += 255u * nff + ((w >> (8u * nff)) & 255u);
+                    at += nff + 1u;
+                    open = false;
+                }
+            }
+            return !open;
+        };
+        if (lit == 15u && !ext(lit, q)) cplx = true;
+        const uint32_t nbl = q - p - 1u, offpos = q + lit;
+        uint32_t mlen = 4u + (t & 15u), q2 = offpos + 2u;
+        if (cplx || offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
+        else if ((t & 15u) == 15u && !ext(mlen, q2)) cplx = true;
+        if (lit > 0xFFFFu || mlen > 0xFFFFu) cplx = true;
+        const uint32_t nxt = q2;
+        const unsigned long long cmask = hb_ballot(cplx);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const uint32_t nrel = cplx ? 64u : nxt - base;
+            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
+            uint32_t j = 0, lastj;
+            for (;;) {
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            const unsigned long long cm = tmask & cmask;
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) { uint2 e; e.x = p | (nbl << 16); e.y = lit | (mlen << 16); s_tq[nq + rank] = e; }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+    }
+    return stop;
+}
+
+__global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) {
+        plan->pad[1] = 0;
+        plan->ok = 0; plan->fail = 0; plan->nreg = nreg; plan->rs = rs; plan->total = 0;
+        uint32_t sh = 0; while (((uint64_t)RG_BUCKETS << sh) < rs) sh++;      // RG_BUCKETS << sh >= rs: every position of a region has a bucket
+        plan->pad[0] = sh;
+    }
+    if (r >= nreg) return;
+    RgRegion R;
+    R.b = r * rs; R.entry = R.b; R.exit = RG_INVALID; R.outlen = 0; R.entry0 = R.b; R.exit0 = RG_INVALID; R.outlen0 = 0; R.ntrace = 0;
+    R.needfull = 1; R.pad0 = 0; R.opos = 0; R.pad1[0] = R.pad1[1] = R.pad1[2] = R.pad1[3] = 0;
+    reg[r] = R;
+}
+
+// ---- (1a) parse a region from its entry to the first token at / after the next region's start; no copies ----
+__global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    const int lane = threadIdx.x;
+    const uint32_t nreg = plan->nreg;
+    if (!first && plan->pad[1] == 0u) return;                            // no region asked for a full parse
+    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+        RgRegion *R = reg + r;
+        if (!RFL(R->needfull)) continue;
+        const uint32_t start = RFL(R->entry);
+        const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)RFL(reg[r + 1].b) : n_src;
+        uint2 *tr = traces + (size_t)r * RG_TRACE;
+        const uint32_t rb = RFL(R->b), bsh = plan->pad[0];                 // bucket = (position - b) >> bsh
+        for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
+        uint64_t si = start, wpos = 0, out = 0;
+        uint32_t wlen = 0, wsh = 0, nq = 0, ntok = 0, exitp = RG_INVALID, lastbk = RG_INVALID;
+        bool invalid = false;
+        auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+            const uint8_t *g = src + at;
+            wsh = (uint32_t)((uintptr_t)g & 15u);
+            const uint64_t left = n_src - at;
+            wlen = (uint32_t)(left < (uint64_t)(RG_PWIN - 16u) ? left : (uint64_t)(RG_PWIN - 16u));
+            const u32x4 *ga = (const u32x4 *)(g - wsh);
+            const uint32_t nv = (wsh + wlen + 15u) >> 4;
+            wave_sync();
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+            wpos = at;
+            wave_sync();
+        };
+        wave_sync();
+        for (;;) {
+            if (si >= bnext) { exitp = (uint32_t)si; break; }           // (si <= n_src always; bnext <= n_src)
+            if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+            uint32_t rel = (uint32_t)(si - wpos);
+            const bool stop = rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
+            bool done = false;
+            while (nq > 0u) {                                           // account for the queued tokens, 64 at a time
+                const uint32_t cntb = nq < 64u ? nq : 64u;
+                const uint2 e = s_tq[lane];
+                const uint32_t lit = e.y & 0xFFFFu, mlen = e.y >> 16;
+                const uint64_t ap = wpos + (e.x & 0xFFFFu);
+                const unsigned long long over = hb_ballot((uint32_t)lane < cntb && ap >= bnext);
+                const uint32_t cnt = over ? (uint32_t)__builtin_ctzll(over) : cntb;
+                const uint32_t olen = (uint32_t)lane < cnt ? lit + mlen : 0u;
+                const uint32_t incl = wave_incl_scan_dpp(olen);
+                const uint32_t idx = ntok + (uint32_t)lane;
+                // trace: the first RG_DENSE tokens, and the first token that starts in each bucket of the region's stream range
+                const uint32_t bk = (uint32_t)lane < cnt ? ((uint32_t)ap - rb) >> bsh : RG_INVALID;
+                const uint32_t pbk = wave_shr1(bk, lastbk);
+                if ((uint32_t)lane < cnt) {
+                    uint2 t; t.x = (uint32_t)ap; t.y = (uint32_t)(out + incl - olen);
+                    if (idx < RG_DENSE) tr[idx] = t;
+                    if (bk != pbk && bk < RG_BUCKETS) tr[RG_DENSE + bk] = t;
+                }
+                if (cnt) lastbk = (uint32_t)__builtin_amdgcn_readlane(bk, (int)cnt - 1);
+                out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                ntok += cnt;
+                if (over) { exitp = RFL(__builtin_amdgcn_readlane((uint32_t)ap, (int)__builtin_ctzll(over))); done = true; nq = 0; break; }
+                const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
+                nq -= cntb;
+                if ((uint32_t)lane < nq) s_tq[lane] = rest;
+            }
+            if (done) break;
+            const bool moved = (wpos + rel) != si;
+            si = wpos + rel;
+            if (moved && !stop) continue;
+            if (si >= bnext) continue;
+            if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src) continue;      // stopped at the window edge: refill first
+            // ---- one token the slow way: length extensions of any size ----
+            if (si < wpos || si >= wpos + wlen) refill(si);
+            rel = (uint32_t)(si - wpos);
+            const uint32_t tokstart = (uint32_t)si;
+            const uint32_t tok = RFL((uint32_t)s_win[wsh + rel]);
+            rel++;
+            uint32_t ll = tok >> 4;
+            {
+                const uint64_t span = n_src - wpos;
+                if (ll == 15u && !dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { invalid = true; break; }
+            }
+            uint64_t p = wpos + rel;
+            if ((uint64_t)ll > n_src - p) { invalid = true; break; }
+            p += ll;
+            uint32_t ml = 0;
+            if (p != n_src) {                                           // (p == n_src: the block's final, literal-only sequence)
+                if (n_src - p < 2) { invalid = true; break; }
+                p += 2;
+                ml = (tok & 15u) + 4u;
+                if ((tok & 15u) == 15u) {
+                    if (p < wpos || p - wpos + 64u > wlen) refill(p);
+                    uint32_t rel2 = (uint32_t)(p - wpos);
+                    const uint64_t span = n_src - wpos;
+                    if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel2, ml, lane)) { invalid = true; break; }
+                    p = wpos + rel2;
+                }
+            }
+            {
+                const uint32_t bk = (tokstart - rb) >> bsh;
+                if (lane == 0) {
+                    uint2 t; t.x = tokstart; t.y = (uint32_t)out;
+                    if (ntok < RG_DENSE) tr[ntok] = t;
+                    if (bk != lastbk && bk < RG_BUCKETS) tr[RG_DENSE + bk] = t;
+                }
+                lastbk = bk;
+            }
+            out += (uint64_t)ll + ml;
+            ntok++;
+            si = p;
+            if (out > 0xFFFFFFF0ull) { invalid = true; break; }
+        }
+        if (out > 0xFFFFFFF0ull) invalid = true;
+        if (lane == 0) {
+            const uint32_t ex = invalid ? RG_INVALID : exitp;
+            R->exit = ex; R->outlen = (uint32_t)out;
+            R->entry0 = start; R->exit0 = ex; R->outlen0 = (uint32_t)out; R->ntrace = ntok < RG_DENSE ? ntok : RG_DENSE;
+            R->needfull = 0;
+        }
+        wave_sync();
+    }
+}
+
+// ---- (1b) settle the chain.  Belief of every region about its first token: the furthest position any predecessor's parse reaches (an
+// exclusive prefix maximum of the exits).  On the true chain exits are monotone, so this is the predecessor's exit; a token that
+// spans many regions (a literal run of MiB) reaches all of them in ONE step instead of one region per step, and the garbage parses
+// of the regions inside such a run (they started at bytes that are literals) are out-voted as long as they stay local.  A region
+// whose belief changed re-parses from the new entry one token at a time until it lands on a position of its recorded trace (the
+// parses have merged: exit unchanged, output length corrected by the difference) or asks for a full parse.  One workgroup, the
+// regions' state in LDS, iterated until nothing moves or a full parse is pending. ----
+__global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces) {
+    __shared__ uint32_t s_entry[RG_MAXREG], s_exit[RG_MAXREG], s_outl[RG_MAXREG], s_need[RG_MAXREG];
+    __shared__ uint32_t s_pm[1024];
+    __shared__ uint32_t s_changed, s_pend;
+    const int t = threadIdx.x;
+    const uint32_t nreg = plan->nreg, bsh = plan->pad[0];
+    constexpr uint32_t PER = RG_MAXREG / 1024;
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t r = (uint32_t)t * PER + k;
+        if (r < nreg) { s_entry[r] = reg[r].entry; s_exit[r] = reg[r].exit; s_outl[r] = reg[r].outlen; s_need[r] = reg[r].needfull; }
+    }
+    if (t == 0) { s_changed = 0; s_pend = 0; }
+    __syncthreads();
+    for (int it = 0; it < 48; it++) {
+        uint32_t mx = 0;
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t r = (uint32_t)t * PER + k; if (r < nreg && s_exit[r] != RG_INVALID) mx = max(mx, s_exit[r]); }
+        s_pm[t] = mx;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t y = t >= d ? s_pm[t - d] : 0u;
+            __syncthreads();
+            s_pm[t] = max(s_pm[t], y);
+            __syncthreads();
+        }
+        uint32_t run = t ? s_pm[t - 1] : 0u;                            // the furthest exit in front of my first region
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t r = (uint32_t)t * PER + k;
+            if (r >= nreg) break;
+            const uint32_t a = run, rb = reg[r].b;
+            bool work = r != 0u && a >= rb;                             // (a < b: no predecessor reaches me yet -- unsettled exits in front of me)
+            if (work && s_need[r] && s_entry[r] == a) work = false;     // a full parse from this entry is already pending
+            if (work && s_entry[r] == a && s_exit[r] != RG_INVALID) work = false;      // belief unchanged
+            if (work) {
+                const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)reg[r + 1].b : n_src;
+                s_entry[r] = a;
+                s_changed = 1;
+                if ((uint64_t)a >= bnext) { s_exit[r] = a; s_outl[r] = 0; s_need[r] = 0; }     // no token of the chain starts in this region
+                else {
+                    const uint2 *tr = traces + (size_t)r * RG_TRACE;
+                    const uint32_t nt = reg[r].ntrace, exit0 = reg[r].exit0, outlen0 = reg[r].outlen0;
+                    uint64_t p = a, cum = 0;
+                    uint32_t ti = 0;
+                    bool settled = false;
+                    for (int iter = 0; iter < 96 && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a full, wave-parallel parse)
+                        if (p >= bnext) { s_exit[r] = (uint32_t)p; s_outl[r] = (uint32_t)cum; s_need[r] = 0; settled = true; break; }
+                        // merged with the recorded parse?  (one of its first tokens, or the first token of a bucket: once the parses have
+                        // merged, this walk visits every token of the recorded one, so it meets a recorded position within a bucket)
+                        while (ti < nt && tr[ti].x < (uint32_t)p) ti++;
+                        uint32_t cum0 = RG_INVALID;
+                        if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
+                        else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
+                        if (cum0 != RG_INVALID) { s_exit[r] = exit0; s_outl[r] = (uint32_t)(cum + (outlen0 - cum0)); s_need[r] = 0; settled = true; break; }
+                        // one token, serially
+                        const uint32_t tok = src[p];
+                        uint64_t q = p + 1, ll = tok >> 4;
+                        bool bad = false;
+                        if (ll == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ll += x; if (x != 255u) break; } }
+                        if (bad || ll > n_src - q) break;
+                        q += ll;
+                        uint64_t ml = 0;
+                        if (q != n_src) {
+                            if (n_src - q < 2) break;
+                            q += 2; ml = (tok & 15u) + 4u;
+                            if ((tok & 15u) == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ml += x; if (x != 255u) break; } }
+                            if (bad) break;
+                        }
+                        cum += ll + ml;
+                        p = q;
+                    }
+                    if (!settled) { s_exit[r] = RG_INVALID; s_need[r] = 1; s_pend = 1; }     // k_rg_parse takes it from `entry`
+                }
+            }
+            if (s_exit[r] != RG_INVALID) run = max(run, s_exit[r]);
+        }
+        __syncthreads();
+        const bool go = s_changed && !s_pend;
+        __syncthreads();
+        if (t == 0) s_changed = 0;
+        __syncthreads();
+        if (!go) break;
+    }
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t r = (uint32_t)t * PER + k;
+        if (r < nreg) { reg[r].entry = s_entry[r]; reg[r].exit = s_exit[r]; reg[r].outlen = s_outl[r]; reg[r].needfull = s_need[r]; }
+    }
+    if (t == 0) plan->pad[1] = s_pend;                                  // full parses pending: the next k_rg_parse has work
+}
+
+// the first round of (1b) has nearly every region re-walk its head: one lane per region over the whole chip instead of one workgroup
+__global__ __launch_bounds__(1024) void k_rg_pmax(RgPlan *plan, const RgRegion *reg, uint32_t *pmax) {
+    __shared__ uint32_t s[1024];
+    const int t = threadIdx.x;
+    const uint32_t nreg = plan->nreg;
+    constexpr uint32_t PER = RG_MAXREG / 1024;
+    uint32_t mine[PER], mx = 0;
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t r = (uint32_t)t * PER + k;
+        uint32_t e = 0;
+        if (r < nreg) { e = reg[r].exit; if (e == RG_INVALID) e = 0; }
+        mine[k] = e;
+        mx = max(mx, e);
+    }
+    s[t] = mx;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t y = t >= d ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] = max(s[t], y);
+        __syncthreads();
+    }
+    uint32_t run = t ? s[t - 1] : 0u;
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t r = (uint32_t)t * PER + k;
+        if (r < nreg) pmax[r] = run;
+        run = max(run, mine[k]);
+    }
+}
+__global__ __launch_bounds__(64) void k_rg_fix(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces,
+                                               const uint32_t *__restrict__ pmax) {
+    const uint32_t nreg = plan->nreg, bsh = plan->pad[0];
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0 || r >= nreg) return;
+    RgRegion *R = reg + r;
+    const uint32_t a = pmax[r], rb = R->b;
+    if (a < rb) return;
+    if (R->entry == a && R->exit != RG_INVALID) return;
+    const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)reg[r + 1].b : n_src;
+    R->entry = a;
+    if ((uint64_t)a >= bnext) { R->exit = a; R->outlen = 0; R->needfull = 0; return; }
+    const uint2 *tr = traces + (size_t)r * RG_TRACE;
+    const uint32_t nt = R->ntrace, exit0 = R->exit0, outlen0 = R->outlen0;
+    uint64_t p = a, cum = 0;
+    uint32_t ti = 0;
+    for (int iter = 0; iter < 96 && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a full, wave-parallel parse)
+        if (p >= bnext) { R->exit = (uint32_t)p; R->outlen = (uint32_t)cum; R->needfull = 0; return; }
+        while (ti < nt && tr[ti].x < (uint32_t)p) ti++;
+        uint32_t cum0 = RG_INVALID;
+        if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
+        else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
+        if (cum0 != RG_INVALID) { R->exit = exit0; R->outlen = (uint32_t)(cum + (outlen0 - cum0)); R->needfull = 0; return; }
+        const uint32_t tok = src[p];
+        uint64_t q = p + 1, ll = tok >> 4;
+        bool bad = false;
+        if (ll == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ll += x; if (x != 255u) break; } }
+        if (bad || ll > n_src - q) break;
+        q += ll;
+        uint64_t ml = 0;
+        if (q != n_src) {
+            if (n_src - q < 2) break;
+            q += 2; ml = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ml += x; if (x != 255u) break; } }
+            if (bad) break;
+        }
+        cum += ll + ml;
+        p = q;
+    }
+    R->exit = RG_INVALID; R->needfull = 1; plan->pad[1] = 1;            // k_rg_parse takes it from `entry`
+}
+
+// ---- (1c) verify the chain, give every region its output position ----
+__global__ __launch_bounds__(1024) void k_rg_scan(RgPlan *plan, RgRegion *reg, uint64_t n_src, uint64_t cap) {
+    __shared__ uint64_t s[1024];
+    __shared__ uint32_t bad;
+    const int t = threadIdx.x;
+    const uint32_t nreg = plan->nreg;
+    if (t == 0) bad = 0;
+    __syncthreads();
+    uint64_t mine[RG_MAXREG / 1024];
+    uint64_t sum = 0;
+    for (uint32_t k = 0; k < RG_MAXREG / 1024; k++) {
+        const uint32_t r = (uint32_t)t * (RG_MAXREG / 1024) + k;
+        mine[k] = 0;
+        if (r < nreg) {
+            const RgRegion R = reg[r];
+            bool ok = !R.needfull && R.exit != RG_INVALID;
+            ok = ok && (r == 0 ? R.entry == 0u : R.entry == reg[r - 1].exit);
+            if (r + 1 == nreg) ok = ok && R.exit == (uint32_t)n_src;
+            if (!ok) atomicOr(&bad, 1u);
+            mine[k] = R.outlen;
+        }
+        sum += mine[k];
+    }
+    s[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint64_t y = t >= d ? s[t - d] : 0ull;
+        __syncthreads();
+        s[t] += y;
+        __syncthreads();
+    }
+    uint64_t o = s[t] - sum;
+    for (uint32_t k = 0; k < RG_MAXREG / 1024; k++) {
+        const uint32_t r = (uint32_t)t * (RG_MAXREG / 1024) + k;
+        if (r < nreg) reg[r].opos = o;
+        o += mine[k];
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint64_t total = s[1023];
+        plan->total = total;
+        if (bad || total > cap || total > 0xFFFFFFF0ull) plan->fail = 1; else plan->ok = 1;
+    }
+}
+
+// ---- (2) with the chain known, write the restart index the encoder would have appended (HBIX, hb_format.h): the decoder's state at
+// every HB_CHUNK bytes of output.  One wavefront per region walks its tokens (window-parallel parser again) with the region's
+// output position in hand; a unit boundary that falls on a token start or inside a literal run becomes an entry; one that falls
+// inside a match (or at its start) means the block was not written chunk-locally: no index, the single wavefront decodes. ----
+__device__ __forceinline__ void rg_emit(uint8_t *ents, uint64_t U, uint32_t s_off, uint32_t lit_rem, uint32_t tok_off) {
+    uint32_t *e = (uint32_t *)(ents + (U / HB_CHUNK) * HB_IDX_ENTRY);
+    e[0] = s_off; e[1] = (uint32_t)U; e[2] = lit_rem; e[3] = tok_off;
+}
+__global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
+                                                 uint8_t *__restrict__ index) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    if (!plan->ok || plan->fail) return;
+    const int lane = threadIdx.x;
+    const uint32_t nreg = plan->nreg;
+    const uint64_t N = plan->total;
+    uint8_t *ents = index + HB_IDX_HDR_BYTES;
+    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+        const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit);
+        if (RFL(reg[r].outlen) == 0u || start >= exitp) continue;
+        uint64_t si = start, wpos = 0, out = reg[r].opos;
+        uint32_t wlen = 0, wsh = 0, nq = 0;
+        bool bad = false;
+        auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+            const uint8_t *g = src + at;
+            wsh = (uint32_t)((uintptr_t)g & 15u);
+            const uint64_t left = n_src - at;
+            wlen = (uint32_t)(left < (uint64_t)(RG_PWIN - 16u) ? left : (uint64_t)(RG_PWIN - 16u));
+            const u32x4 *ga = (const u32x4 *)(g - wsh);
+            const uint32_t nv = (wsh + wlen + 15u) >> 4;
+            wave_sync();
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+            wpos = at;
+            wave_sync();
+        };
+        wave_sync();
+        while (!bad && si < exitp) {
+            if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+            uint32_t rel = (uint32_t)(si - wpos);
+            const uint64_t tolim = (uint64_t)exitp - wpos;
+            const uint32_t lim = (uint32_t)(tolim < (uint64_t)wlen ? tolim : (uint64_t)wlen);
+            const bool stop = rg_fill(s_win, wsh, lim, rel, nq, s_tq, lane);
+            while (nq > 0u) {
+                const uint32_t cntb = nq < 64u ? nq : 64u;
+                const uint2 e = s_tq[lane];
+                const uint32_t lit = e.y & 0xFFFFu, mlen = e.y >> 16;
+                const uint32_t tp = (uint32_t)(wpos + (e.x & 0xFFFFu)), ls = tp + 1u + (e.x >> 16);
+                const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
+                const uint32_t incl = wave_incl_scan_dpp(olen);
+                const uint64_t d0 = out + incl - olen;                   // where my sequence's output starts
+                uint64_t U = (d0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);            // first unit boundary at / after it
+                bool inm = false;
+                if ((uint32_t)lane < cntb) {
+                    if (U == d0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
+                    for (; U < d0 + lit && U < N; U += HB_CHUNK) rg_emit(ents, U, ls + (uint32_t)(U - d0), (uint32_t)(d0 + lit - U), tp);
+                    if (U < d0 + lit + mlen && U < N) inm = true;       // a unit boundary at the start of / inside a match
+                }
+                if (hb_ballot(inm)) { bad = true; nq = 0; break; }
+                out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+                const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
+                nq -= cntb;
+                if ((uint32_t)lane < nq) s_tq[lane] = rest;
+            }
+            if (bad) break;
+            const bool moved = (wpos + rel) != si;
+            si = wpos + rel;
+            if (moved && !stop) continue;
+            if (si >= exitp) break;
+            if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src && wpos + wlen < exitp) continue;
+            // ---- one token the slow way: runs of any length ----
+            if (si < wpos || si >= wpos + wlen) refill(si);
+            rel = (uint32_t)(si - wpos);
+            const uint32_t tp = (uint32_t)si;
+            const uint32_t tok = RFL((uint32_t)s_win[wsh + rel]);
+            rel++;
+            uint32_t ll = tok >> 4;
+            {
+                const uint64_t span = n_src - wpos;
+                if (ll == 15u && !dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { bad = true; break; }
+            }
+            uint64_t p = wpos + rel;
+            const uint32_t ls = (uint32_t)p;
+            if ((uint64_t)ll > n_src - p) { bad = true; break; }
+            p += ll;
+            uint32_t ml = 0;
+            if (p != n_src) {
+                if (n_src - p < 2) { bad = true; break; }
+                p += 2;
+                ml = (tok & 15u) + 4u;
+                if ((tok & 15u) == 15u) {
+                    if (p < wpos || p - wpos + 64u > wlen) refill(p);
+                    uint32_t rel2 = (uint32_t)(p - wpos);
+                    const uint64_t span = n_src - wpos;
+                    if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel2, ml, lane)) { bad = true; break; }
+                    p = wpos + rel2;
+                }
+            }
+            {   // unit boundaries of this sequence: token start, inside the literal run (any number of them), never in the match
+                const uint64_t d0 = out, U0 = (d0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+                if (U0 == d0 && U0 < N && lane == 0) rg_emit(ents, U0, tp, HB_IDX_AT_TOKEN, 0u);
+                for (uint64_t U = (U0 == d0 ? U0 + HB_CHUNK : U0) + (uint64_t)lane * HB_CHUNK; U < d0 + ll && U < N; U += 64ull * HB_CHUNK)
+                    rg_emit(ents, U, ls + (uint32_t)(U - d0), (uint32_t)(d0 + ll - U), tp);
+                const uint64_t m0 = d0 + ll, Um = (m0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+                if (ml && Um < m0 + ml && Um < N) bad = true;            // a boundary at the start of / inside the match
+            }
+            out += (uint64_t)ll + ml;
+            si = p;
+        }
+        if (bad && lane == 0) atomicExch(&plan->fail, 1u);
+        wave_sync();
+    }
+}
+
+// first entry, terminator and header (written last: a failed build leaves the zeroed header, which k_dec_plan rejects)
+__global__ void k_rg_index_head(RgPlan *plan, uint8_t *__restrict__ index, uint64_t n_src) {
+    if (!plan->ok || plan->fail) return;
+    const uint64_t N = plan->total;
+    const uint32_t nunits = (uint32_t)((N + HB_CHUNK - 1) / HB_CHUNK);
+    if (nunits == 0) return;
+    uint32_t *e = (uint32_t *)(index + HB_IDX_HDR_BYTES);
+    e[0] = 0; e[1] = 0; e[2] = HB_IDX_AT_TOKEN; e[3] = 0;
+    uint32_t *t = e + 4 * (size_t)nunits;
+    t[0] = (uint32_t)n_src; t[1] = (uint32_t)N; t[2] = 0; t[3] = 0;
+    uint32_t *h = (uint32_t *)index;
+    h[0] = HB_IDX_MAGIC; h[1] = HB_IDX_VERSION | (HB_IDX_ENTRY << 16); h[2] = nunits; h[3] = HB_CHUNK;
+    h[4] = (uint32_t)n_src; h[5] = (uint32_t)N; h[6] = 0;
+    h[7] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5];
+}
+
+// Builds the restart index of an index-less block in the workspace; *index / *index_bytes then go to k_dec_plan / k_dec_indexed as if
+// the frame had carried them (an index that could not be built stays zeroed and is rejected there: serial decode).
+int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size_t *index_bytes, hipStream_t s) {
+    const RgLayout L = rg_layout();
+    uint8_t *w = a.work + 256;                                          // behind the DecPlan
+    RgPlan *plan = (RgPlan *)(w + L.plan);
+    RgRegion *reg = (RgRegion *)(w + L.reg);
+    uint2 *traces = (uint2 *)(w + L.trace);
+    uint8_t *idx = w + L.total;                                         // hb_lz4_index_bound(cap) bytes behind the fixed part
+    const size_t ib = hb_lz4_index_bound(a.cap);
+    uint64_t rs = (a.n + RG_MAXREG - 1) / RG_MAXREG;
+    if (rs < RG_MINREG) rs = RG_MINREG;
+    rs = (rs + 15) & ~(uint64_t)15;
+    const uint32_t nreg = (uint32_t)((a.n + rs - 1) / rs);
+    HB_HIP_TRY(hipMemsetAsync(idx, 0, ib, s));
+    hb_prof_begin("k_rg_parse", s);
+    hipLaunchKernelGGL(k_rg_init, dim3((nreg + 255) / 256), dim3(256), 0, s, plan, reg, nreg, (uint32_t)rs);
+    hipLaunchKernelGGL(k_rg_parse, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 1);
+    hb_prof_end(s);
+    hb_prof_begin("k_rg_fix", s);
+    hipLaunchKernelGGL(k_rg_pmax, dim3(1), dim3(1024), 0, s, plan, reg, (uint32_t *)(w + L.pmax));
+    hipLaunchKernelGGL(k_rg_fix, dim3((nreg + 63) / 64), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, (const uint32_t *)(w + L.pmax));
+    hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
+    hb_prof_end(s);
+    hb_prof_begin("k_rg_settle", s);
+    for (int k = 0; k < RG_FIXROUNDS; k++) {
+        hipLaunchKernelGGL(k_rg_settle, dim3(1), dim3(1024), 0, s, a.src, (uint64_t)a.n, plan, reg, traces);
+        if (k + 1 < RG_FIXROUNDS)                                       // regions that asked for a full parse (returns at once when none did)
+            hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
+    }
+    hipLaunchKernelGGL(k_rg_scan, dim3(1), dim3(1024), 0, s, plan, reg, (uint64_t)a.n, (uint64_t)a.cap);
+    hb_prof_end(s);
+    hb_prof_begin("k_rg_index", s);
+    hipLaunchKernelGGL(k_rg_index, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, idx);
+    hipLaunchKernelGGL(k_rg_index_head, dim3(1), dim3(1), 0, s, plan, idx, (uint64_t)a.n);
+    hb_prof_end(s);
+    HB_HIP_TRY(hipGetLastError());
+    *index = idx; *index_bytes = ib;
+    return HB_OK;
+}

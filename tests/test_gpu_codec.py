@@ -260,8 +260,11 @@ def test_multi_tile_frames_use_the_index(hb, O):
         if not hb.GetInfo(f).IsMemcpy():
             assert hb.lib().hb_last_result_flags() & 1, f"{name}: indexed decoder rejected its own index"
         cb = hb.GetInfo(f).NBytesComp
-        assert hb.Decompress(f[:cb]) == x.tobytes(), f"{name}: serial decode (index cut off) differs"
-        assert not (hb.lib().hb_last_result_flags() & 1)
+        assert hb.Decompress(f[:cb]) == x.tobytes(), f"{name}: decode with the index cut off differs"
+        # without the trailer: payloads from 256 KiB up get their index rebuilt on the device (csrc/hb_lz4_region.hip), smaller ones
+        # are decoded by the single wavefront
+        rebuilt = (not hb.GetInfo(f).IsMemcpy()) and cb - 16 >= (256 << 10)
+        assert bool(hb.lib().hb_last_result_flags() & 1) == rebuilt, name
 
 
 @pytest.mark.parametrize("ts", [2, 4, 8])

@@ -1,0 +1,167 @@
+"""GPU parity: frames WITHOUT a restart index.
+
+Two kinds exist.  (1) Frames this library writes without HB_OPT_INDEX_TRAILER (the drop-in default: a reference frame ends at
+NBytesComp): their matches never leave a 4 KiB chunk, so the device rebuilds the index from the stream (guess-and-verify token
+discovery, csrc/hb_lz4_region.hip) and decodes chunk-parallel.  (2) Frames the REFERENCE writes (one LZ4 block, 64 KiB window,
+codec.go:63-75 -- here: the oracle's restatement of lz4.CompressBlock, and liblz4 as a second foreign parse): the rebuilt index
+cannot hold for them (matches cross every chunk boundary), the single wavefront decodes; what matters is that the attempt never
+changes a byte or an error.  Expected bytes: the oracle decoder's (the restated reference `Decompress`).
+"""
+import ctypes
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _liblz4():
+    for p in ("/usr/lib/x86_64-linux-gnu/liblz4.so.1", "/opt/conda/lib/liblz4.so.1"):
+        if os.path.exists(p):
+            return ctypes.CDLL(p)
+    return None
+
+
+def _cases(O):
+    rng = np.random.default_rng(2026)
+    f32 = O.synth(O.D_F32, (24 << 20) // 4 + 3)
+    out = {
+        # name: (data, shuffle, typesize, expect the parallel path)
+        "f32_24MiB_shuffle": (f32, 1, 4, True),
+        "f32_24MiB_noshuffle": (f32, 0, 1, None),                     # (barely compressible: may be a memcpy frame)
+        "f64_16MiB_shuffle8": (O.synth(O.D_F64, (16 << 20) // 8), 1, 8, True),
+        "i32_16MiB_bitshuffle": (O.synth(O.D_I32, (16 << 20) // 4), 2, 4, True),
+        "ramp_8MiB": (O.synth(O.D_RAMP, (8 << 20) // 4 + 1), 1, 4, None),            # tiny payload: long matches, few tokens
+        "few_valued_12MiB": (rng.integers(0, 4, 12 << 20, dtype=np.uint8) * 64, 0, 1, True),      # token-dense, short offsets
+        "period_8192": (np.tile(rng.integers(0, 256, 8192, dtype=np.uint8), 1500), 0, 1, None),   # matches chain period by period
+        "noisy_period": (None, 0, 1, None),
+        "rand_then_zeros_then_text": (np.concatenate([rng.integers(0, 256, (3 << 20) + 5, dtype=np.uint8), np.zeros((9 << 20) + 1, np.uint8),
+                                                      np.frombuffer((b"the quick brown fox jumps over the lazy dog. " * 90000), np.uint8),
+                                                      rng.integers(0, 256, 70001, dtype=np.uint8), np.full(3 << 20, 7, np.uint8)]), 0, 1, None),
+        "far_offsets": (None, 0, 1, None),
+    }
+    base = np.tile(rng.integers(0, 256, 8192, dtype=np.uint8), 1200)
+    noise = rng.integers(0, base.size, base.size // 300)
+    base[noise] ^= 0x5A
+    out["noisy_period"] = (base, 0, 1, None)
+    # blocks of 40 KiB random bytes, each repeated once 40 KiB later: every match reaches 40960 bytes back (beyond the LDS history)
+    blk = [rng.integers(0, 256, 40960, dtype=np.uint8) for _ in range(60)]
+    out["far_offsets"] = (np.concatenate([np.concatenate([b, b]) for b in blk]), 0, 1, None)
+    return out
+
+
+def test_reference_shaped_frames_decode_exactly(hb, O):
+    for name, (x, shuffle, ts, _) in _cases(O).items():
+        f = O.compress_frame(x, shuffle=shuffle, typesize=ts)
+        want = O.decompress_frame(f)
+        assert np.array_equal(want, x.view(np.uint8).reshape(-1))
+        assert hb.Decompress(f.tobytes()) == x.tobytes(), name
+
+
+def test_own_frames_without_the_trailer_decode_in_parallel(hb, O):
+    # what Compress() returns by default (opts = 0): the index is rebuilt on the device and checked like a stored one
+    for name, (x, shuffle, ts, _) in _cases(O).items():
+        f = hb.Compress(x.tobytes(), hb.LZ4, 5, shuffle, ts, opts=0)
+        h = hb.ParseHeader(f)
+        assert len(f) == h.NBytesComp                                   # nothing behind the frame
+        assert O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes() == x.tobytes(), name
+        assert hb.Decompress(f) == x.tobytes(), name
+        if not h.IsMemcpy() and h.NBytesComp - 16 >= (256 << 10):
+            assert hb.lib().hb_last_result_flags() & 1, f"{name}: the rebuilt index was not used"
+        with_index = hb.Compress(x.tobytes(), hb.LZ4, 5, shuffle, ts, opts=hb.OPT_INDEX_TRAILER)
+        assert with_index[:h.NBytesComp] == f                            # same frame, the trailer is only appended
+    # LZ4HC frames are LZ4 blocks too
+    x = _cases(O)["f32_24MiB_shuffle"][0]
+    f = hb.Compress(x.tobytes(), hb.LZ4HC, 9, hb.Shuffle1, 4, opts=0)
+    assert hb.Decompress(f) == x.tobytes() and hb.lib().hb_last_result_flags() & 1
+
+
+def test_liblz4_blocks_decode_exactly(hb, O):
+    # a second foreign encoder (different parse: LZ4_compress_default), wrapped in a go-blosc header by hand
+    lz = _liblz4()
+    if lz is None:
+        pytest.skip("liblz4 not in this image")
+    rng = np.random.default_rng(5)
+    for name, x in {"f32_shuffled": O.filter(O.OP_SHUFFLE, O.synth(O.D_F32, (16 << 20) // 4), 4),
+                    "text": np.frombuffer(b"".join(bytes(str(i * 7919 % 100003), "ascii") + b", " for i in range(1500000)), np.uint8),
+                    "few_valued": rng.integers(0, 3, 10 << 20, dtype=np.uint8)}.items():
+        n = x.size
+        cap = lz.LZ4_compressBound(n)
+        b = ctypes.create_string_buffer(cap)
+        c = lz.LZ4_compress_default(x.tobytes(), b, n, cap)
+        assert 0 < c < n
+        frame = struct.pack("<BBBBIII", 2, hb.LZ4, 0, 1, n, n, 16 + c) + b.raw[:c]
+        assert O.decompress_frame(np.frombuffer(frame, np.uint8)).tobytes() == x.tobytes()
+        assert hb.Decompress(frame) == x.tobytes(), name
+        # the bare-block entry point (the codec plugin seam, codec.go:77-84)
+        assert hb.codecs[hb.LZ4].Decompress(b.raw[:c], n) == x.tobytes(), name
+
+
+def test_malformed_foreign_frames_report_what_the_reference_reports(hb, O):
+    # large index-less frames with damage: the region decoder must step aside and the result (error class or bytes) must be
+    # the restated reference decoder's
+    by_code = {-1: hb.ErrInvalidData, -2: hb.ErrInvalidHeader, -3: hb.ErrInvalidVersion, -4: hb.ErrInvalidCodec,
+               -5: hb.ErrSizeMismatch, -8: hb.ErrDecompressionFailed}
+    rng = np.random.default_rng(77)
+    x = O.synth(O.D_F32, (2 << 20) // 4)
+    for f in (O.compress_frame(x, shuffle=1, typesize=4).tobytes(), hb.Compress(x.tobytes(), hb.LZ4, 5, hb.Shuffle1, 4, opts=0)):
+        _mutations_agree(hb, O, f, by_code, rng)
+
+
+def _mutations_agree(hb, O, f, by_code, rng):
+    cb = hb.ParseHeader(f).NBytesComp
+    assert cb > (512 << 10)
+    for trial in range(40):
+        g = bytearray(f)
+        kind = trial % 5
+        if kind == 0:
+            g[int(rng.integers(16, cb))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            pos = int(rng.integers(16, cb - 8))
+            g[pos:pos + 8] = rng.integers(0, 256, 8, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            cut = int(rng.integers(cb // 2, cb))
+            g = g[:cut]; g[12:16] = struct.pack("<I", cut)
+        elif kind == 3:
+            g[4:8] = struct.pack("<I", int.from_bytes(g[4:8], "little") + int(rng.integers(-3000, 3000)))
+        else:
+            pos = int(rng.integers(16, cb - 2))
+            g[pos:pos + 2] = b"\x00\x00"                                  # very likely an offset 0 somewhere on the chain
+        g = bytes(g)
+        try:
+            want = (None, O.decompress_frame(np.frombuffer(g, np.uint8)).tobytes())
+        except O.OracleError as e:
+            want = (by_code[e.code], None)
+        try:
+            got = (None, hb.Decompress(g))
+        except hb.BloscError as e:
+            got = (type(e), None)
+        assert got[0] is want[0], (trial, kind, got[0], want[0])
+        if want[1] is not None:
+            assert got[1] == want[1], (trial, kind)
+
+
+def test_index_less_frames_at_full_size(hb, O):
+    # BASELINE.json's headline frame without the trailer: written by this library (index rebuilt, parallel decode) and as the
+    # reference would have written it (single wavefront; 256 MiB of it, to keep the test in seconds)
+    import time
+    L = hb.lib()
+    n = 1 << 30
+    x = O.synth(O.D_F32, n // 4)
+    cap = L.hb_frame_bound(n)
+    out = np.empty(cap, np.uint8)
+    c = L.hb_compress_frame(x.ctypes.data, n, out.ctypes.data, cap, hb.LZ4, 5, hb.Shuffle1, 4, 0, 0)
+    assert c == hb.ParseHeader(out[:16].tobytes()).NBytesComp
+    back = np.empty(n, np.uint8)
+    t0 = time.perf_counter()
+    assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, n, 0, 0) == n
+    dt = time.perf_counter() - t0
+    assert L.hb_last_result_flags() & 1, "the rebuilt index was not used on the 1 GiB frame"
+    assert np.array_equal(back, x), "decode through the rebuilt index differs from the input at full size"
+    print(f"index-less 1 GiB frame host->host: {n / dt / 1e9:.2f} GB/s")
+    m = 256 << 20
+    f = O.compress_frame(x[:m], shuffle=1, typesize=4)
+    assert L.hb_decompress_frame(f.ctypes.data, f.size, back.ctypes.data, m, 0, 0) == m
+    assert np.array_equal(back[:m], x[:m]), "reference-shaped frame: device decode differs"
