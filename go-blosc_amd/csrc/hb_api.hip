@@ -306,6 +306,64 @@ int64_t hb_lz4_decompress(const void *src, size_t n, void *dst, size_t cap, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// the codec plugin seam for every device codec: CodecInterface.Compress / Decompress (codec.go:15-24) on bare blocks
+// ------------------------------------------------------------------------------------------
+size_t hb_codec_bound(int codec, size_t n) { return hb_device_codec(codec) ? hb_lz4_bound(n) + 16 : 0; }
+
+int64_t hb_codec_compress(int codec, int level, const void *src, size_t n, void *dst, size_t cap, int device) {
+    if (!hb_device_codec(codec)) return HB_ERR_INVALID_CODEC;
+    if (codec == HB_LZ4) return hb_lz4_compress(src, n, dst, cap, device);          // codec.go:63-75 (level ignored)
+    if ((!src && n) || !dst) return HB_ERR_BAD_ARG;
+    if (n == 0) {                                                        // lz4hc: nothing to write; snappy.Encode(nil, empty) = uvarint(0)
+        if (codec == HB_LZ4HC) return 0;
+        if (cap < 1) return HB_ERR_SHORT_BUFFER;
+        *(uint8_t *)dst = 0;
+        return 1;
+    }
+    if (n > 0xFFFFFFFFull - HB_HEADER_SIZE - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
+    int rc = select_device(device);
+    if (rc) return rc;
+    Scratch sc(device);
+    const size_t fb = hb_frame_bound(n), wb = hb_compress_frame_workspace(n);
+    uint8_t *d_src = sc.get(n + 16), *d_frame = sc.get(fb + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_src || !d_frame || !d_work || !d_res) return HB_ERR_HIP;
+    HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
+    // the frame path without a filter and without the memcpy rule: the payload behind the 16 header bytes is the block
+    rc = hb_compress_frame_dev(d_src, n, d_frame, fb + 64, codec, level, HB_NOSHUFFLE, 1, HB_OPT_INTERNAL_BLOCK, d_work, wb, (hb_result *)d_res, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;
+    const size_t c = (size_t)r.bytes - HB_HEADER_SIZE;
+    if (c > cap) return HB_ERR_SHORT_BUFFER;
+    HB_HIP_TRY(hipMemcpy(dst, d_frame + HB_HEADER_SIZE, c, hipMemcpyDeviceToHost));
+    return (int64_t)c;
+}
+
+int64_t hb_codec_decompress(int codec, const void *src, size_t n, void *dst, size_t cap, int device) {
+    if (!hb_device_codec(codec)) return HB_ERR_INVALID_CODEC;
+    if (codec != HB_SNAPPY) return hb_lz4_decompress(src, n, dst, cap, device);     // codec.go:77-84, :120-128 (same block format)
+    if ((!src && n) || (!dst && cap)) return HB_ERR_BAD_ARG;
+    if (n == 0) return HB_ERR_DECOMPRESSION_FAILED;                     // snappy.Decode of an empty slice: corrupt (no length)
+    int rc = select_device(device);
+    if (rc) return rc;
+    Scratch sc(device);
+    const size_t wb = hb_lz4_dec_workspace(cap);
+    uint8_t *d_src = sc.get(n + 64), *d_dst = sc.get(cap + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_src || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
+    HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
+    hb_dec_args a{};
+    a.src = d_src; a.n = n; a.dst = d_dst; a.cap = cap; a.work = d_work; a.result = (hb_result *)d_res; a.frame = 0;
+    rc = hb_launch_snappy_decode(a, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;                                      // (a declared length above cap: HB_ERR_SHORT_BUFFER)
+    if (r.bytes) HB_HIP_TRY(hipMemcpy(dst, d_dst, r.bytes, hipMemcpyDeviceToHost));
+    return (int64_t)r.bytes;
+}
+
+// ------------------------------------------------------------------------------------------
 // frame layer
 // ------------------------------------------------------------------------------------------
 size_t hb_compress_frame_workspace(size_t n) { return hb_lz4_enc_workspace(n) + ((n + 255) & ~(size_t)255) + 256; }

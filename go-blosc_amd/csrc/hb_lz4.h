@@ -4,6 +4,8 @@
 
 #include "hb_format.h"
 
+#define HB_OPT_INTERNAL_BLOCK 0x80000000u   // hb_codec_compress: no memcpy rule -- the payload is always the codec's block
+
 struct hb_enc_args {
     const uint8_t *src; size_t n;        // bytes to encode (already filtered)
     uint8_t *dst; size_t cap;            // frame != 0: frame start (payload at +16); else the block itself

@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256) void k_scan(const Agg *__restrict__ tile_agg, 
         uint32_t use_memcpy = 0;
         uint64_t payload = C;
         if (fi.frame) {
-            use_memcpy = C >= n;                                      // blosc.go:342
+            use_memcpy = !(fi.opts & HB_OPT_INTERNAL_BLOCK) && C >= n;  // blosc.go:342 (the codec seam wants the block itself, always)
             if (use_memcpy) payload = n;
             uint8_t flags = 0;                                        // blosc.go:348-356
             if (fi.shuffle == HB_SHUFFLE) flags |= HB_FLAG_SHUFFLE;
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_sn_scan(const Agg *__restrict__ tile_ag
         const uint64_t C = hl + carry;
         plan->cbytes_block = C;
         plan->nchunks = nchunks;
-        const uint32_t use_memcpy = C >= n;                           // blosc.go:342
+        const uint32_t use_memcpy = !(fi.opts & HB_OPT_INTERNAL_BLOCK) && C >= n;      // blosc.go:342
         const uint64_t payload = use_memcpy ? n : C;
         uint8_t flags = 0;                                            // blosc.go:348-356
         if (fi.shuffle == HB_SHUFFLE) flags |= HB_FLAG_SHUFFLE;

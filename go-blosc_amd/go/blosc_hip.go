@@ -4,7 +4,7 @@
 // filters and the LZ4 codec on an MI355X through libhipblosc.so (include/hipblosc.h).
 //
 // It plugs into the reference's own two seams and changes nothing else:
-//   * the codec plugin seam      codec.go:15-38   RegisterCodec(LZ4, hipLZ4{})
+//   * the codec plugin seam      codec.go:15-38   RegisterCodec(LZ4 / LZ4HC / Snappy, ...)
 //   * the filter hook seam       shuffle.go:26-57, :154-174 (hooks declared in shuffle_amd64.go:21-41,
 //                                stubs in shuffle_generic.go:15-52)  ->  the four xxxHIP functions below
 // plus an optional fused fast path (CompressHIP / DecompressHIP) that replaces compressBackend /
@@ -51,6 +51,8 @@ func init() {
 	useHIP = C.hb_init() == C.HB_OK && C.hb_device_count() > 0
 	if useHIP {
 		RegisterCodec(LZ4, &hipLZ4{fallback: &lz4Codec{}}) // codec.go:36-38
+		RegisterCodec(LZ4HC, &hipCodec{id: LZ4HC, name: "lz4hc", fallback: &lz4hcCodec{}})
+		RegisterCodec(Snappy, &hipCodec{id: Snappy, name: "snappy", fallback: &snappyCodec{}})
 	}
 }
 
@@ -115,6 +117,42 @@ func (c *hipLZ4) Decompress(data []byte, expectedSize int) ([]byte, error) {
 	n := C.hb_lz4_decompress(ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)), C.int(Device))
 	if n < 0 {
 		return nil, fmt.Errorf("lz4 decompress: %w", hbError(n))
+	}
+	return buf[:n], nil
+}
+
+// hipCodec: the same seam for blosc.LZ4HC (codec.go:90-128; `level` picks the search depth) and blosc.Snappy (codec.go:228-244).
+type hipCodec struct {
+	id       Codec
+	name     string
+	fallback CodecInterface
+}
+
+func (c *hipCodec) Name() string { return c.name } // codec.go:92, :230
+
+func (c *hipCodec) Compress(data []byte, level int) ([]byte, error) {
+	if !useHIP || len(data) < MinOffloadBytes {
+		return c.fallback.Compress(data, level)
+	}
+	buf := make([]byte, int(C.hb_codec_bound(C.int(c.id), C.size_t(len(data)))))
+	n := C.hb_codec_compress(C.int(c.id), C.int(level), ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)), C.int(Device))
+	if n < 0 {
+		return nil, fmt.Errorf("%s compress: %w", c.name, hbError(n)) // codec.go:113-115
+	}
+	return buf[:n], nil
+}
+
+func (c *hipCodec) Decompress(data []byte, expectedSize int) ([]byte, error) {
+	if !useHIP || expectedSize < MinOffloadBytes {
+		return c.fallback.Decompress(data, expectedSize)
+	}
+	buf := make([]byte, expectedSize)
+	n := C.hb_codec_decompress(C.int(c.id), ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)), C.int(Device))
+	if n == C.HB_ERR_SHORT_BUFFER { // a Snappy block that declares more than expectedSize: snappy.Decode would allocate (codec.go:238)
+		return c.fallback.Decompress(data, expectedSize)
+	}
+	if n < 0 {
+		return nil, fmt.Errorf("%s decompress: %w", c.name, hbError(n))
 	}
 	return buf[:n], nil
 }

@@ -84,7 +84,7 @@ EXPORTS = [
     "hb_init", "hb_device_count", "hb_shutdown", "hb_pool_limit", "hb_pool_cached_bytes", "hb_strerror", "hb_version", "hb_host_alloc", "hb_host_free",
     "hb_filter", "hb_filter_dev", "hb_lz4_bound", "hb_lz4_compress", "hb_lz4_decompress",
     "hb_lz4_compress_workspace", "hb_lz4_decompress_workspace", "hb_lz4_compress_dev", "hb_lz4_decompress_dev",
-    "hb_index_bound", "hb_parse_header", "hb_header_bytes", "hb_frame_bound", "hb_compress_frame",
+    "hb_index_bound", "hb_codec_bound", "hb_codec_compress", "hb_codec_decompress", "hb_parse_header", "hb_header_bytes", "hb_frame_bound", "hb_compress_frame",
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
@@ -122,7 +122,8 @@ def lib():
             "hb_host_alloc": (vp, [sz]), "hb_host_free": (None, [vp]),
             "hb_filter": (i32, [i32, vp, vp, sz, i32, i32]),
             "hb_filter_dev": (i32, [i32, vp, vp, sz, i32, vp]),
-            "hb_lz4_bound": (sz, [sz]), "hb_index_bound": (sz, [sz]),
+            "hb_lz4_bound": (sz, [sz]), "hb_index_bound": (sz, [sz]), "hb_codec_bound": (sz, [i32, sz]),
+            "hb_codec_compress": (i64, [i32, i32, vp, sz, vp, sz, i32]), "hb_codec_decompress": (i64, [i32, vp, sz, vp, sz, i32]),
             "hb_lz4_compress": (i64, [vp, sz, vp, sz, i32]),
             "hb_lz4_decompress": (i64, [vp, sz, vp, sz, i32]),
             "hb_lz4_compress_workspace": (sz, [sz]), "hb_lz4_decompress_workspace": (sz, [sz]),
@@ -345,7 +346,32 @@ class HipLZ4Codec:
         return out.raw[:rc]
 
 
-codecs = {LZ4: HipLZ4Codec()}              # codec.go:27-33 (only the LZ4 codec lives on the device path)
+class HipDeviceCodec:
+    """CodecInterface (codec.go:15-24) for LZ4HC (codec.go:90-128) and Snappy (codec.go:228-244) backed by hb_codec_*."""
+
+    def __init__(self, codec, name):
+        self.codec, self.name = codec, name
+
+    def Name(self):
+        return self.name
+
+    def Compress(self, data, level):
+        p, n, keep = _buf(data)
+        L = lib()
+        cap = L.hb_codec_bound(self.codec, n)
+        out = ctypes.create_string_buffer(cap)
+        rc = _check(L.hb_codec_compress(self.codec, level, p, n, ctypes.cast(out, ctypes.c_void_p), cap, device))
+        return out.raw[:rc]
+
+    def Decompress(self, data, expectedSize):
+        p, n, keep = _buf(data)
+        out = ctypes.create_string_buffer(max(expectedSize, 1))
+        rc = _check(lib().hb_codec_decompress(self.codec, p, n, ctypes.cast(out, ctypes.c_void_p), expectedSize, device))
+        return out.raw[:rc]
+
+
+# codec.go:27-33: the codecs that live on the device path (ZLIB is not built; ZSTD is a host codec behind hb_compress_frame)
+codecs = {LZ4: HipLZ4Codec(), LZ4HC: HipDeviceCodec(LZ4HC, "lz4hc"), Snappy: HipDeviceCodec(Snappy, "snappy")}
 
 
 def RegisterCodec(id, codec):              # codec.go:36-38

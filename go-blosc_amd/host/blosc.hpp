@@ -155,8 +155,25 @@ struct HipLZ4Codec : CodecInterface {                                           
         return out;
     }
 };
+struct HipDeviceCodec : CodecInterface {                                  // replaces lz4hcCodec (codec.go:90-128) / snappyCodec (:228-244)
+    Codec codec; std::string name; int device = 0;
+    HipDeviceCodec(Codec c, std::string n) : codec(c), name(std::move(n)) {}
+    std::string Name() const override { return name; }
+    Bytes Compress(const Bytes &data, int level) override {
+        Bytes out(hb_codec_bound(codec, data.size()));
+        out.resize((size_t)check(hb_codec_compress(codec, level, data.data(), data.size(), out.data(), out.size(), device)));
+        return out;
+    }
+    Bytes Decompress(const Bytes &data, int expectedSize) override {
+        Bytes out(expectedSize > 0 ? expectedSize : 1);
+        out.resize((size_t)check(hb_codec_decompress(codec, data.data(), data.size(), out.data(), (size_t)expectedSize, device)));
+        return out;
+    }
+};
 inline std::map<Codec, std::shared_ptr<CodecInterface>> &registry() {
-    static std::map<Codec, std::shared_ptr<CodecInterface>> r{{LZ4, std::make_shared<HipLZ4Codec>()}};
+    static std::map<Codec, std::shared_ptr<CodecInterface>> r{{LZ4, std::make_shared<HipLZ4Codec>()},
+                                                              {LZ4HC, std::make_shared<HipDeviceCodec>(LZ4HC, "lz4hc")},
+                                                              {Snappy, std::make_shared<HipDeviceCodec>(Snappy, "snappy")}};
     return r;
 }
 inline std::mutex &registry_mu() { static std::mutex m; return m; }                        // the reference's map is unguarded (codec.go:36-38)

@@ -138,6 +138,16 @@ int hb_lz4_decompress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
                           void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
 size_t  hb_index_bound(size_t n);   /* bytes of restart index for an n-byte block */
 
+/* ---- the same seam for every codec that runs on the device: the CodecInterface of blosc.LZ4 (codec.go:59-84), blosc.LZ4HC
+ *      (codec.go:90-128: `level` picks the search depth like the reference's level map) and blosc.Snappy (codec.go:228-244).
+ *      Bare blocks, no frame header; Compress always returns the codec's block (no memcpy rule here: that is the frame layer's,
+ *      blosc.go:342).  hb_codec_decompress returns the decoded length (Snappy: the length the block declares; a declared length
+ *      above `cap` is HB_ERR_SHORT_BUFFER -- the reference would allocate), HB_ERR_DECOMPRESSION_FAILED on a malformed block,
+ *      HB_ERR_INVALID_CODEC for a codec that has no device implementation. ---- */
+size_t  hb_codec_bound(int codec, size_t n);
+int64_t hb_codec_compress(int codec, int level, const void *src, size_t n, void *dst, size_t cap, int device);
+int64_t hb_codec_decompress(int codec, const void *src, size_t n, void *dst, size_t cap, int device);
+
 /* ---- frame layer: replaces compressBackend / decompressBackend (blosc.go:320-434) behind
  *      CompressWithOptions / DecompressWithSize (blosc.go:268-303) ---- */
 int     hb_parse_header(const void *frame, size_t n, hb_header *out);                 /* ParseHeader, blosc.go:165-185 */

@@ -235,3 +235,53 @@ def test_f3_codecs_through_the_queue_and_at_full_size(hb, O):
         ratios[(codec, level)] = h.NBytesComp / n
     q.close()
     assert ratios[(hb.LZ4HC, 9)] < ratios[(hb.LZ4HC, 5)] < ratios[(hb.LZ4, 5)] < ratios[(hb.Snappy, 5)] + 0.2, ratios
+
+
+def test_codec_seam_bare_blocks(hb, O):
+    # CodecInterface (codec.go:15-24) for the two f3 codecs: Compress gives the codec's own block -- never the input back, the
+    # memcpy rule is the frame layer's (blosc.go:342) -- and Decompress takes any block of that format
+    lz, sn = _liblz4(), _libsnappy()
+    rng = np.random.default_rng(3)
+    sets = dict(_cases(O))
+    sets["f32_5MiB"] = O.synth(O.D_F32, (5 << 20) // 4 + 1)
+    hc, sy = hb.codecs[hb.LZ4HC], hb.codecs[hb.Snappy]
+    assert (hc.Name(), sy.Name()) == ("lz4hc", "snappy")                # codec.go:92, :230
+    for name, x in sets.items():
+        xb = x.tobytes()
+        for level in (1, 9):
+            b = hc.Compress(xb, level)
+            assert O.lz4_decompress(np.frombuffer(b, np.uint8), len(xb)).tobytes() == xb, (name, level)
+            assert hc.Decompress(b, len(xb)) == xb, (name, level)
+            if lz is not None:
+                back = ctypes.create_string_buffer(len(xb) + 1)
+                assert lz.LZ4_decompress_safe(b, back, len(b), len(xb)) == len(xb) and back.raw[:len(xb)] == xb, (name, level)
+        b = sy.Compress(xb, 5)
+        assert O.snappy_decompress(np.frombuffer(b, np.uint8), len(xb)).tobytes() == xb, name
+        assert sy.Decompress(b, len(xb)) == xb, name
+        if sn is not None:
+            ln = ctypes.c_size_t(len(xb) + 1)
+            back = ctypes.create_string_buffer(len(xb) + 1)
+            assert sn.snappy_uncompress(b, len(b), back, ctypes.byref(ln)) == 0 and back.raw[:ln.value] == xb, name
+            # the other way: the format library's block through the device decoder
+            cap = sn.snappy_max_compressed_length(len(xb)); cl = ctypes.c_size_t(cap)
+            fb = ctypes.create_string_buffer(cap)
+            assert sn.snappy_compress(xb, len(xb), fb, ctypes.byref(cl)) == 0
+            assert sy.Decompress(fb.raw[:cl.value], len(xb)) == xb, name
+    # random bytes: the frame layer would store them, the codec still returns a block (longer than the input)
+    r = rng.integers(0, 256, 300000, dtype=np.uint8).tobytes()
+    assert len(hc.Compress(r, 9)) > len(r) and len(sy.Compress(r, 5)) > len(r)
+    # empty input: snappy.Encode gives the one length byte, an LZ4 block of nothing is nothing
+    assert sy.Compress(b"", 5) == b"\x00" and sy.Decompress(b"\x00", 0) == b""
+    assert hc.Compress(b"", 9) == b""
+    # errors: a declared length above the caller's size, a cut block, a codec without a device implementation
+    b = sy.Compress(sets["f32_1MiB"].tobytes(), 5)
+    with pytest.raises(hb.BloscError):
+        sy.Decompress(b, 1000)
+    with pytest.raises(hb.ErrDecompressionFailed):
+        sy.Decompress(b[:len(b) // 2], sets["f32_1MiB"].nbytes)
+    with pytest.raises(hb.ErrDecompressionFailed):
+        hc.Decompress(hc.Compress(sets["f64"].tobytes(), 9)[:-3], sets["f64"].nbytes)
+    L = hb.lib()
+    buf = ctypes.create_string_buffer(64)
+    assert L.hb_codec_bound(hb.ZSTD, 100) == 0
+    assert L.hb_codec_compress(hb.ZSTD, 5, buf, 8, buf, 64, 0) == -4       # HB_ERR_INVALID_CODEC (codec.go:46-55 GetCodec)
