@@ -237,6 +237,7 @@ int hb_filter(int op, void *dst, const void *src, size_t n, int typesize, int de
 // ------------------------------------------------------------------------------------------
 size_t hb_lz4_compress_workspace(size_t n) { return hb_lz4_enc_workspace(n); }
 size_t hb_lz4_decompress_workspace(size_t n_out) { return hb_lz4_dec_workspace(n_out); }
+size_t hb_lz4_decompress_workspace_foreign(size_t n_out) { return ((hb_lz4_dec_workspace(n_out) + 255) & ~(size_t)255) + hb_lz4_sym_workspace(n_out); }
 
 int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap, void *d_index, size_t index_cap,
                         void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
@@ -262,6 +263,7 @@ int hb_lz4_decompress_dev(const void *d_src, size_t n, void *d_dst, size_t cap, 
     a.src = (const uint8_t *)d_src; a.n = n; a.dst = (uint8_t *)d_dst; a.cap = cap;
     a.index = (const uint8_t *)d_index; a.index_bytes = index_bytes;
     a.work = (uint8_t *)d_work; a.result = d_result; a.frame = 0;
+    if (work_bytes >= hb_lz4_decompress_workspace_foreign(cap)) a.sym_work = (uint8_t *)d_work + ((hb_lz4_dec_workspace(cap) + 255) & ~(size_t)255);
     return hb_launch_lz4_decode(a, (hipStream_t)stream);
 }
 
@@ -292,7 +294,7 @@ int64_t hb_lz4_decompress(const void *src, size_t n, void *dst, size_t cap, int 
     if ((!src && n) || (!dst && cap)) return HB_ERR_BAD_ARG;
     if (n == 0) return 0;                                             // UncompressBlock: empty src -> 0, nil
     Scratch sc(device);
-    const size_t wb = hb_lz4_dec_workspace(cap);
+    const size_t wb = n >= (256u << 10) ? hb_lz4_decompress_workspace_foreign(cap) : hb_lz4_dec_workspace(cap);   // (a bare block never has an index)
     uint8_t *d_src = sc.get(n + 64), *d_dst = sc.get(cap + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
     if (!d_src || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
     HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
@@ -368,6 +370,9 @@ int64_t hb_codec_decompress(int codec, const void *src, size_t n, void *dst, siz
 // ------------------------------------------------------------------------------------------
 size_t hb_compress_frame_workspace(size_t n) { return hb_lz4_enc_workspace(n) + ((n + 255) & ~(size_t)255) + 256; }
 size_t hb_decompress_frame_workspace(size_t n_out) { return hb_lz4_dec_workspace(n_out) + ((n_out + 255) & ~(size_t)255) + 256; }
+// the same plus the scratch of the symbolic decoder: with it, LZ4 frames that carry no index and were not written by this library
+// (one block with a 64 KiB window: what the reference writes) decode in parallel too (hb_lz4_sym.hip)
+size_t hb_decompress_frame_workspace_foreign(size_t n_out) { return ((hb_decompress_frame_workspace(n_out) + 255) & ~(size_t)255) + hb_lz4_sym_workspace(n_out); }
 
 int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap, int codec, int level, int shuffle,
                           int typesize, unsigned opts, void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
@@ -476,6 +481,8 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     a.staged = staged;
     if (fused_bun || fused_ush) unf = -1;                             // nothing left to do after the decoder
     if (stored_index) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }
+    if (!snappy && work_bytes >= hb_decompress_frame_workspace_foreign(h.nbytes))
+        a.sym_work = work + ((hb_decompress_frame_workspace(h.nbytes) + 255) & ~(size_t)255);
     rc = snappy ? hb_launch_snappy_decode(a, s) : hb_launch_lz4_decode(a, s);
     if (rc) return rc;
     if (unf >= 0) {
@@ -535,7 +542,10 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     if (rc) return rc;
     if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
     Scratch sc(device);
-    const size_t wb = hb_decompress_frame_workspace(h.nbytes);
+    // an LZ4 frame without an index behind NBytesComp may be anybody's: room for the symbolic decoder as well
+    const bool maybe_foreign = !(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && (size_t)h.cbytes - HB_HEADER_SIZE >= (256u << 10) &&
+                               n <= (((size_t)h.cbytes + 7) & ~(size_t)7) + 32;
+    const size_t wb = maybe_foreign ? hb_decompress_frame_workspace_foreign(h.nbytes) : hb_decompress_frame_workspace(h.nbytes);
     uint8_t *d_frame = sc.get(n + 64), *d_dst = sc.get((size_t)h.nbytes + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
     if (!d_frame || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
     HB_HIP_TRY(hipMemcpy(d_frame, frame, n, hipMemcpyHostToDevice));

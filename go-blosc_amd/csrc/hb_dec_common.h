@@ -19,6 +19,8 @@ enum { DEC_SERIAL = 0, DEC_INDEXED = 1 };
 size_t hb_lz4_region_workspace(size_t n_out);
 bool hb_lz4_region_wanted(const hb_dec_args &a);
 int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size_t *index_bytes, hipStream_t s);
+// hb_lz4_sym.hip: decodes a block whose rebuilt index did not hold (a foreign block) from the verified token chain
+int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_work, int mark_post, hipStream_t s);
 
 #define DTQ 96                           // token queue slots: < 64 queued before a window is parsed; a 64-byte window adds <= 22 LZ4 tokens or <= 32 Snappy elements
 

@@ -30,6 +30,7 @@ struct hb_dec_args {
     int fused_bitunshuffle4;             // the frame is bitshuffled with typesize 4 and the un-filter runs inside the decoder
     int fused_unshuffle_ts;              // != 0: the frame is byte-shuffled with this typesize and the un-shuffle runs inside the decoder
     uint8_t *staged;                     // fused un-filter: where the serial fallback puts the still-filtered bytes
+    uint8_t *sym_work;                   // hb_lz4_sym_workspace(cap) bytes, or NULL: foreign blocks then stay with the single wavefront
 };
 
 // hb_zstd.hip: host ZSTD behind the device filter (BASELINE.json config 5)
@@ -45,6 +46,7 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
 size_t hb_lz4_enc_workspace(size_t n);
 size_t hb_lz4_dec_workspace(size_t n_out);
 size_t hb_lz4_index_bound(size_t n);
+size_t hb_lz4_sym_workspace(size_t n_out);      // hb_lz4_sym.hip: scratch of the symbolic decoder of foreign blocks (~2 bytes per output byte)
 int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s);
 int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s);
 // hb_snappy.hip: Snappy block decoder (codec.go:237-244); same argument record, the fused un-filter fields are ignored

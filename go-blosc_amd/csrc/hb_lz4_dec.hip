@@ -519,6 +519,12 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
     // produces filtered bytes, so it goes to the staging buffer and the gated un-filter pass finishes the job
     const int fused_any = a.fused_bitunshuffle4 || a.fused_unshuffle_ts;
     uint8_t *serial_dst = fused_any ? a.staged : a.dst;
+    // a block without an index whose rebuilt index did not hold was written by someone else (the reference: one block, 64 KiB
+    // window): decoded in parallel from the verified token chain, symbolically (hb_lz4_sym.hip); no-op when the index held
+    if (hb_lz4_region_wanted(a) && a.sym_work) {
+        const int rc = hb_launch_lz4_sym_decode(a, serial_dst, a.sym_work, fused_any, s);
+        if (rc) return rc;
+    }
     hb_prof_begin("k_dec_serial", s);
     hipLaunchKernelGGL(k_dec_serial, dim3(1), dim3(64), 0, s, a.src, (uint64_t)a.n, serial_dst, (uint64_t)a.cap, plan,
                        a.result, a.frame, a.expect, fused_any);

@@ -1,0 +1,199 @@
+// hb_lz4_region.h — state of the guess-and-verify token discovery (hb_lz4_region.hip) shared with the symbolic decoder of
+// foreign blocks (hb_lz4_sym.hip): the regions of the stream, their verified token chain, the window-parallel parser.
+#pragma once
+#include "hb_lz4.h"
+#include "hb_dec_common.h"
+
+#define RG_TRACE    256u          // trace entries per region: RG_DENSE first tokens + one per bucket of the region's stream range
+#define RG_DENSE    128u
+#define RG_BUCKETS  128u
+#define RG_INVALID  0xFFFFFFFFu
+#define RG_MAXREG   4096u
+#define RG_MINREG   65536u        // smallest region, stream bytes
+#define RG_PWIN     8192u         // parse window
+#define RG_FIXROUNDS 4             // k_rg_settle launches (each iterates to a standstill), full parses in between
+
+struct __attribute__((aligned(16))) RgRegion {
+    uint32_t b;          // nominal start (stream position)
+    uint32_t entry;      // belief: first token of this region (>= b of the next region: the region is empty)
+    uint32_t exit;       // first token at / after the next region's b when parsing from `entry`; RG_INVALID: parse failed
+    uint32_t outlen;     // output bytes of the tokens in [entry, exit)
+    uint32_t entry0, exit0, outlen0, ntrace;   // the parse the trace belongs to
+    uint32_t needfull;   // full parse from `entry` pending
+    uint32_t pad0;
+    uint64_t opos;       // output position of `entry`
+    uint32_t pad1[4];
+};
+struct RgPlan { uint32_t ok, fail, nreg, rs; uint64_t total; uint32_t pad[10]; };
+
+struct RgLayout { size_t plan, reg, pmax, trace, total; };
+static inline RgLayout rg_layout() {
+    RgLayout L; size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
+    L.plan = take(sizeof(RgPlan));
+    L.reg = take((size_t)RG_MAXREG * sizeof(RgRegion));
+    L.pmax = take((size_t)RG_MAXREG * 4);
+    L.trace = take((size_t)RG_MAXREG * RG_TRACE * sizeof(uint2));
+    L.total = o;
+    return L;
+}
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+
+// Window-parallel token parser for the passes that copy nothing.  Like dec_fill (hb_dec_common.h), but every lane also sums
+// multi-byte length extensions itself (up to 24 bytes each, i.e. lengths up to 6 KiB): a stream made of long runs (20-byte
+// sequences, each with a 16-byte match extension) would otherwise go through the one-token path sequence by sequence.
+// Queue entry: { tokpos | nbl << 16, lit | mlen << 16 }, positions relative to the window; literal bytes start at tokpos + 1 + nbl.
+__device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si == lim) { stop = true; break; }
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t t = p < lim ? (uint32_t)s_in[sh + p] : 0u;
+        bool cplx = p >= lim;
+        uint32_t lit = t >> 4, q = p + 1u;
+        // a length extension, four bytes per step (a lane that sits inside a run of 0xFF -- every byte of a long extension looks like
+        // the start of another one -- gives up after 24 bytes instead of crawling through it)
+        auto ext = [&](uint32_t &len, uint32_t &at) __attribute__((always_inline)) {
+            bool open = true;
+            for (int k = 0; k < 6 && open; k++) {
+                if (at + 4u > lim) break;
+                const uint32_t w = dec_read4(s_in, sh + at);
+                if (w == 0xFFFFFFFFu) { len += 1020u; at += 4u; }
+                else {
+                    const uint32_t nff = (uint32_t)__builtin_ctz(~w) >> 3;
+                    len += 255u * nff + ((w >> (8u * nff)) & 255u);
+                    at += nff + 1u;
+                    open = false;
+                }
+            }
+            return !open;
+        };
+        if (lit == 15u && !ext(lit, q)) cplx = true;
+        const uint32_t nbl = q - p - 1u, offpos = q + lit;
+        uint32_t mlen = 4u + (t & 15u), q2 = offpos + 2u;
+        if (cplx || offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
+        else if ((t & 15u) == 15u && !ext(mlen, q2)) cplx = true;
+        if (lit > 0xFFFFu || mlen > 0xFFFFu) cplx = true;
+        const uint32_t nxt = q2;
+        const unsigned long long cmask = hb_ballot(cplx);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const uint32_t nrel = cplx ? 64u : nxt - base;
+            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
+            uint32_t j = 0, lastj;
+            for (;;) {
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            const unsigned long long cm = tmask & cmask;
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) { uint2 e; e.x = p | (nbl << 16); e.y = lit | (mlen << 16); s_tq[nq + rank] = e; }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+    }
+    return stop;
+}
+
+
+// regions of an n-byte stream: at most RG_MAXREG, at least RG_MINREG bytes each
+static inline void rg_regions(size_t n, uint64_t *rs_out, uint32_t *nreg_out) {
+    uint64_t rs = (n + RG_MAXREG - 1) / RG_MAXREG;
+    if (rs < RG_MINREG) rs = RG_MINREG;
+    rs = (rs + 15) & ~(uint64_t)15;
+    *rs_out = rs; *nreg_out = (uint32_t)((n + rs - 1) / rs);
+}
+
+// Walks the tokens of [start, exitp) of a VERIFIED chain (k_rg_scan passed: every length extension ends inside the stream, exitp is
+// a token start or the end of the block), one wavefront.  Tokens the window-parallel parser takes come 64 at a time, one per lane:
+//   batch(cnt, tp, ls, lit, mlen, off)   lane < cnt holds a token at stream position tp with `lit` literals at ls, then a match of
+//                                        mlen >= 4 bytes at distance off; returns false (wave-uniform) to stop the walk
+// the rest one at a time with all arguments wave-uniform:
+//   single(tp, ls, lit, mlen, off, tok)  mlen == 0: the block's final, literal-only sequence
+// Returns false when a callback stopped the walk or the stream turned out malformed after all.
+template <class Batch, class Single>
+__device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const uint64_t n_src, const uint32_t start, const uint32_t exitp,
+                                        uint8_t *s_win /* RG_PWIN + 128 */, uint2 *s_tq /* DTQ */, const int lane, Batch &&batch, Single &&single) {
+    uint64_t si = start, wpos = 0;
+    uint32_t wlen = 0, wsh = 0, nq = 0;
+    auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+        const uint8_t *g = src + at;
+        wsh = (uint32_t)((uintptr_t)g & 15u);
+        const uint64_t left = n_src - at;
+        wlen = (uint32_t)(left < (uint64_t)(RG_PWIN - 16u) ? left : (uint64_t)(RG_PWIN - 16u));
+        const u32x4 *ga = (const u32x4 *)(g - wsh);
+        const uint32_t nv = (wsh + wlen + 15u) >> 4;
+        wave_sync();
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+        wpos = at;
+        wave_sync();
+    };
+    wave_sync();
+    while (si < exitp) {
+        if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+        uint32_t rel = (uint32_t)(si - wpos);
+        const uint64_t tolim = (uint64_t)exitp - wpos;
+        const uint32_t lim = (uint32_t)(tolim < (uint64_t)wlen ? tolim : (uint64_t)wlen);
+        const bool stop = rg_fill(s_win, wsh, lim, rel, nq, s_tq, lane);
+        while (nq > 0u) {
+            const uint32_t cntb = nq < 64u ? nq : 64u;
+            const uint2 e = s_tq[lane];
+            const uint32_t lit = e.y & 0xFFFFu, mlen = e.y >> 16;
+            const uint32_t tw = e.x & 0xFFFFu, lw = tw + 1u + (e.x >> 16);       // token / first literal, window-relative
+            uint32_t off = 0;
+            if ((uint32_t)lane < cntb) off = (uint32_t)s_win[wsh + lw + lit] | ((uint32_t)s_win[wsh + lw + lit + 1u] << 8);
+            const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
+            if (!batch(cntb, (uint32_t)wpos + tw, (uint32_t)wpos + lw, lit, mlen, off)) return false;
+            nq -= cntb;
+            if ((uint32_t)lane < nq) s_tq[lane] = rest;
+        }
+        const bool moved = (wpos + rel) != si;
+        si = wpos + rel;
+        if (moved && !stop) continue;
+        if (si >= exitp) break;
+        if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src && wpos + wlen < exitp) continue;
+        // ---- one token the slow way: runs of any length ----
+        if (si < wpos || si >= wpos + wlen) refill(si);
+        rel = (uint32_t)(si - wpos);
+        const uint32_t tp = (uint32_t)si;
+        const uint32_t tok = RFL((uint32_t)s_win[wsh + rel]);
+        rel++;
+        uint32_t ll = tok >> 4;
+        {
+            const uint64_t span = n_src - wpos;
+            if (ll == 15u && !dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) return false;
+        }
+        uint64_t p = wpos + rel;
+        const uint32_t ls = (uint32_t)p;
+        if ((uint64_t)ll > n_src - p) return false;
+        p += ll;
+        uint32_t ml = 0, off = 0;
+        if (p != n_src) {
+            if (n_src - p < 2) return false;
+            off = RFL((uint32_t)src[p] | ((uint32_t)src[p + 1] << 8));
+            p += 2;
+            ml = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u) {
+                if (p < wpos || p - wpos + 64u > wlen) refill(p);
+                uint32_t rel2 = (uint32_t)(p - wpos);
+                const uint64_t span = n_src - wpos;
+                if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel2, ml, lane)) return false;
+                p = wpos + rel2;
+            }
+        }
+        if (!single(tp, ls, ll, ml, off, tok)) return false;
+        si = p;
+    }
+    return true;
+}

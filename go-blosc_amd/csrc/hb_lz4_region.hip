@@ -28,114 +28,11 @@
 //
 // Everything malformed (offset 0, offset before the block, lengths running off the stream, output beyond cap) only raises
 // plan->fail; k_dec_serial then decodes the block and reports what lz4.UncompressBlock would report.
-#include "hb_lz4.h"
-#include "hb_dec_common.h"
+#include "hb_lz4_region.h"
 
-#define RG_TRACE    256u          // trace entries per region: RG_DENSE first tokens + one per bucket of the region's stream range
-#define RG_DENSE    128u
-#define RG_BUCKETS  128u
-#define RG_INVALID  0xFFFFFFFFu
-#define RG_MAXREG   4096u
-#define RG_MINREG   65536u        // smallest region, stream bytes
-#define RG_PWIN     8192u         // parse window
-#define RG_FIXROUNDS 4             // k_rg_settle launches (each iterates to a standstill), full parses in between
-
-struct __attribute__((aligned(16))) RgRegion {
-    uint32_t b;          // nominal start (stream position)
-    uint32_t entry;      // belief: first token of this region (>= b of the next region: the region is empty)
-    uint32_t exit;       // first token at / after the next region's b when parsing from `entry`; RG_INVALID: parse failed
-    uint32_t outlen;     // output bytes of the tokens in [entry, exit)
-    uint32_t entry0, exit0, outlen0, ntrace;   // the parse the trace belongs to
-    uint32_t needfull;   // full parse from `entry` pending
-    uint32_t pad0;
-    uint64_t opos;       // output position of `entry`
-    uint32_t pad1[4];
-};
-struct RgPlan { uint32_t ok, fail, nreg, rs; uint64_t total; uint32_t pad[10]; };
-
-struct RgLayout { size_t plan, reg, pmax, trace, total; };
-static inline RgLayout rg_layout() {
-    RgLayout L; size_t o = 0;
-    auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
-    L.plan = take(sizeof(RgPlan));
-    L.reg = take((size_t)RG_MAXREG * sizeof(RgRegion));
-    L.pmax = take((size_t)RG_MAXREG * 4);
-    L.trace = take((size_t)RG_MAXREG * RG_TRACE * sizeof(uint2));
-    L.total = o;
-    return L;
-}
 size_t hb_lz4_region_workspace(size_t n_out) { return rg_layout().total + ((hb_lz4_index_bound(n_out) + 255) & ~(size_t)255); }
 // blocks below 256 KiB stay with the single wavefront (a dozen launches cost more than they save)
 bool hb_lz4_region_wanted(const hb_dec_args &a) { return !a.index && !a.memcpy_payload && a.n >= (256u << 10) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull; }
-
-#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-
-// Window-parallel token parser for the passes that copy nothing.  Like dec_fill (hb_dec_common.h), but every lane also sums
-// multi-byte length extensions itself (up to 24 bytes each, i.e. lengths up to 6 KiB): a stream made of long runs (20-byte
-// sequences, each with a 16-byte match extension) would otherwise go through the one-token path sequence by sequence.
-// Queue entry: { tokpos | nbl << 16, lit | mlen << 16 }, positions relative to the window; literal bytes start at tokpos + 1 + nbl.
-__device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
-    bool stop = false;
-    while (nq < 64u && !stop) {
-        if (si == lim) { stop = true; break; }
-        const uint32_t base = si, p = base + (uint32_t)lane;
-        const uint32_t t = p < lim ? (uint32_t)s_in[sh + p] : 0u;
-        bool cplx = p >= lim;
-        uint32_t lit = t >> 4, q = p + 1u;
-        // a length extension, four bytes per step (a lane that sits inside a run of 0xFF -- every byte of a long extension looks like
-        // the start of another one -- gives up after 24 bytes instead of crawling through it)
-        auto ext = [&](uint32_t &len, uint32_t &at) __attribute__((always_inline)) {
-            bool open = true;
-            for (int k = 0; k < 6 && open; k++) {
-                if (at + 4u > lim) break;
-                const uint32_t w = dec_read4(s_in, sh + at);
-                if (w == 0xFFFFFFFFu) { len += 1020u; at += 4u; }
-                else {
-                    const uint32_t nff = (uint32_t)__builtin_ctz(~w) >> 3;
-                    len += 255u * nff + ((w >> (8u * nff)) & 255u);
-                    at += nff + 1u;
-                    open = false;
-                }
-            }
-            return !open;
-        };
-        if (lit == 15u && !ext(lit, q)) cplx = true;
-        const uint32_t nbl = q - p - 1u, offpos = q + lit;
-        uint32_t mlen = 4u + (t & 15u), q2 = offpos + 2u;
-        if (cplx || offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
-        else if ((t & 15u) == 15u && !ext(mlen, q2)) cplx = true;
-        if (lit > 0xFFFFu || mlen > 0xFFFFu) cplx = true;
-        const uint32_t nxt = q2;
-        const unsigned long long cmask = hb_ballot(cplx);
-        unsigned long long tmask = 0;
-        uint32_t cur;
-        {
-            const uint32_t nrel = cplx ? 64u : nxt - base;
-            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
-            uint32_t j = 0, lastj;
-            for (;;) {
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
-                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
-                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
-                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
-                j = __builtin_amdgcn_readlane(succ, (int)j3);
-                lastj = j3;
-                if (j == j3) break;
-            }
-            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
-            const unsigned long long cm = tmask & cmask;
-            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
-        }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-        if ((tmask >> lane) & 1ull) { uint2 e; e.x = p | (nbl << 16); e.y = lit | (mlen << 16); s_tq[nq + rank] = e; }
-        nq += (uint32_t)__builtin_popcountll(tmask);
-        si = cur;
-    }
-    return stop;
-}
 
 __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -623,10 +520,8 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     uint2 *traces = (uint2 *)(w + L.trace);
     uint8_t *idx = w + L.total;                                         // hb_lz4_index_bound(cap) bytes behind the fixed part
     const size_t ib = hb_lz4_index_bound(a.cap);
-    uint64_t rs = (a.n + RG_MAXREG - 1) / RG_MAXREG;
-    if (rs < RG_MINREG) rs = RG_MINREG;
-    rs = (rs + 15) & ~(uint64_t)15;
-    const uint32_t nreg = (uint32_t)((a.n + rs - 1) / rs);
+    uint64_t rs; uint32_t nreg;
+    rg_regions(a.n, &rs, &nreg);
     HB_HIP_TRY(hipMemsetAsync(idx, 0, ib, s));
     hb_prof_begin("k_rg_parse", s);
     hipLaunchKernelGGL(k_rg_init, dim3((nreg + 255) / 256), dim3(256), 0, s, plan, reg, nreg, (uint32_t)rs);

@@ -85,7 +85,7 @@ EXPORTS = [
     "hb_filter", "hb_filter_dev", "hb_lz4_bound", "hb_lz4_compress", "hb_lz4_decompress",
     "hb_lz4_compress_workspace", "hb_lz4_decompress_workspace", "hb_lz4_compress_dev", "hb_lz4_decompress_dev",
     "hb_index_bound", "hb_codec_bound", "hb_codec_compress", "hb_codec_decompress", "hb_parse_header", "hb_header_bytes", "hb_frame_bound", "hb_compress_frame",
-    "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace",
+    "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace", "hb_decompress_frame_workspace_foreign", "hb_lz4_decompress_workspace_foreign",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
     "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_queue_create", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
@@ -134,7 +134,8 @@ def lib():
             "hb_frame_bound": (sz, [sz]),
             "hb_compress_frame": (i64, [vp, sz, vp, sz, i32, i32, i32, i32, u32, i32]),
             "hb_decompress_frame": (i64, [vp, sz, vp, sz, i32, i32]),
-            "hb_compress_frame_workspace": (sz, [sz]), "hb_decompress_frame_workspace": (sz, [sz]),
+            "hb_compress_frame_workspace": (sz, [sz]), "hb_decompress_frame_workspace": (sz, [sz]), "hb_decompress_frame_workspace_foreign": (sz, [sz]),
+            "hb_lz4_decompress_workspace_foreign": (sz, [sz]),
             "hb_compress_frame_dev": (i32, [vp, sz, vp, sz, i32, i32, i32, i32, u32, vp, sz, vp, vp]),
             "hb_decompress_frame_dev": (i32, [vp, sz, vp, sz, i32, vp, sz, vp, vp]),
             "hb_compress_frames_multi": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, u32]),

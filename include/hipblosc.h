@@ -125,6 +125,7 @@ int64_t hb_lz4_decompress(const void *src, size_t n, void *dst, size_t cap, int 
 
 size_t  hb_lz4_compress_workspace(size_t n);
 size_t  hb_lz4_decompress_workspace(size_t n_out);
+size_t  hb_lz4_decompress_workspace_foreign(size_t n_out);   /* see hb_decompress_frame_workspace_foreign */
 /* async; d_index (may be NULL) receives the restart index for this block, index_cap bytes available (see hb_index_bound) */
 int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
                         void *d_index, size_t index_cap,
@@ -167,6 +168,11 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap,
 
 size_t  hb_compress_frame_workspace(size_t n);
 size_t  hb_decompress_frame_workspace(size_t n_out);
+/* the same plus ~2 bytes per output byte: with a workspace of this size an LZ4 / LZ4HC frame that has no restart index and was
+ * not written chunk-locally (what the reference's lz4.CompressBlock writes, codec.go:63-75) is decoded in parallel as well
+ * (symbolic decode from the verified token chain); with the smaller workspace such a frame goes to one wavefront.  The host-pointer
+ * entry points pick the size themselves. */
+size_t  hb_decompress_frame_workspace_foreign(size_t n_out);
 int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap,
                           int codec, int level, int shuffle, int typesize, unsigned opts,
                           void *d_work, size_t work_bytes, hb_result *d_result, void *stream);

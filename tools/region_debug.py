@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--typesize", type=int, default=4)
     ap.add_argument("--writer", default="oracle", choices=["oracle", "device"],
                     help="oracle: the restated reference encoder (64 KiB window); device: this library WITHOUT the index trailer")
+    ap.add_argument("--small-work", action="store_true", help="workspace without the symbolic decoder's scratch (foreign frames then decode on one wavefront)")
+    ap.add_argument("--reps", type=int, default=1)
     a = ap.parse_args()
     L = hb.lib()
     assert L.hb_init() == 0
@@ -46,15 +48,20 @@ def main():
     pad = torch.zeros(64, dtype=torch.uint8, device=dev)
     d_frame = torch.cat([d_frame, pad])
     d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
-    wb = L.hb_decompress_frame_workspace(n)
+    wb = L.hb_decompress_frame_workspace(n) if a.small_work else L.hb_decompress_frame_workspace_foreign(n)
     work = torch.zeros(wb, dtype=torch.uint8, device=dev)
     res = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    L.hb_profile_enable(1)
-    rc = L.hb_decompress_frame_dev(d_frame.data_ptr(), f.size, d_out.data_ptr(), n, 0, work.data_ptr(), wb, res.data_ptr(), stream)
-    torch.cuda.synchronize()
-    st = bench.stage_times()
-    L.hb_profile_enable(0)
+    import time
+    for rep in range(a.reps):
+        L.hb_profile_enable(1)
+        t0 = time.perf_counter()
+        rc = L.hb_decompress_frame_dev(d_frame.data_ptr(), f.size, d_out.data_ptr(), n, 0, work.data_ptr(), wb, res.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = bench.stage_times()
+        L.hb_profile_enable(0)
+        print(f"rep {rep}: {dt * 1e3:.2f} ms wall with profiling events = {n / dt / 1e9:.1f} GB/s")
     r = res.cpu().numpy().view(np.uint8)
     print("rc", rc, "status", int(r[:4].view(np.int32)[0]), "flags", int(r[4:8].view(np.uint32)[0]), "bytes", int(r[8:16].view(np.uint64)[0]))
     print("ratio", f.size / n, "stage ms", {k: round(sum(v), 3) for k, v in st.items()})
