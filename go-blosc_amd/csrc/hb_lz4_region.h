@@ -20,7 +20,7 @@ struct __attribute__((aligned(16))) RgRegion {
     uint32_t outlen;     // output bytes of the tokens in [entry, exit)
     uint32_t entry0, exit0, outlen0, ntrace;   // the parse the trace belongs to
     uint32_t needfull;   // full parse from `entry` pending
-    uint32_t pad0;
+    uint32_t pad0;       // from this stream position on the recorded parse (the trace) runs on the region's final chain
     uint64_t opos;       // output position of `entry`
     uint32_t pad1[4];
 };
@@ -117,8 +117,8 @@ static inline void rg_regions(size_t n, uint64_t *rs_out, uint32_t *nreg_out) {
 
 // Walks the tokens of [start, exitp) of a VERIFIED chain (k_rg_scan passed: every length extension ends inside the stream, exitp is
 // a token start or the end of the block), one wavefront.  Tokens the window-parallel parser takes come 64 at a time, one per lane:
-//   batch(cnt, tp, ls, lit, mlen, off)   lane < cnt holds a token at stream position tp with `lit` literals at ls, then a match of
-//                                        mlen >= 4 bytes at distance off; returns false (wave-uniform) to stop the walk
+//   batch(cnt, tp, ls, lit, mlen, off, lp)  lane < cnt holds a token at stream position tp with `lit` literals at ls (staged at
+//                                        s_win[lp]), then a match of mlen >= 4 bytes at distance off; returns false (wave-uniform) to stop the walk
 // the rest one at a time with all arguments wave-uniform:
 //   single(tp, ls, lit, mlen, off, tok)  mlen == 0: the block's final, literal-only sequence
 // Returns false when a callback stopped the walk or the stream turned out malformed after all.
@@ -139,14 +139,10 @@ __device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const u
         wpos = at;
         wave_sync();
     };
-    wave_sync();
-    while (si < exitp) {
-        if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
-        uint32_t rel = (uint32_t)(si - wpos);
-        const uint64_t tolim = (uint64_t)exitp - wpos;
-        const uint32_t lim = (uint32_t)(tolim < (uint64_t)wlen ? tolim : (uint64_t)wlen);
-        const bool stop = rg_fill(s_win, wsh, lim, rel, nq, s_tq, lane);
-        while (nq > 0u) {
+    // queued tokens go to `batch` 64 at a time; fewer only when the order demands it (before the window moves: queue entries are
+    // window-relative; before a token takes the slow path; at the end)
+    auto drain = [&](const bool all) __attribute__((always_inline)) -> bool {
+        while (nq >= 64u || (all && nq > 0u)) {
             const uint32_t cntb = nq < 64u ? nq : 64u;
             const uint2 e = s_tq[lane];
             const uint32_t lit = e.y & 0xFFFFu, mlen = e.y >> 16;
@@ -154,13 +150,24 @@ __device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const u
             uint32_t off = 0;
             if ((uint32_t)lane < cntb) off = (uint32_t)s_win[wsh + lw + lit] | ((uint32_t)s_win[wsh + lw + lit + 1u] << 8);
             const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
-            if (!batch(cntb, (uint32_t)wpos + tw, (uint32_t)wpos + lw, lit, mlen, off)) return false;
+            if (!batch(cntb, (uint32_t)wpos + tw, (uint32_t)wpos + lw, lit, mlen, off, wsh + lw)) return false;
             nq -= cntb;
             if ((uint32_t)lane < nq) s_tq[lane] = rest;
         }
+        return true;
+    };
+    wave_sync();
+    while (si < exitp) {
+        if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) { if (!drain(true)) return false; refill(si); } }
+        uint32_t rel = (uint32_t)(si - wpos);
+        const uint64_t tolim = (uint64_t)exitp - wpos;
+        const uint32_t lim = (uint32_t)(tolim < (uint64_t)wlen ? tolim : (uint64_t)wlen);
+        const bool stop = rg_fill(s_win, wsh, lim, rel, nq, s_tq, lane);
+        if (!drain(false)) return false;
         const bool moved = (wpos + rel) != si;
         si = wpos + rel;
         if (moved && !stop) continue;
+        if (!drain(true)) return false;
         if (si >= exitp) break;
         if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src && wpos + wlen < exitp) continue;
         // ---- one token the slow way: runs of any length ----
@@ -195,5 +202,5 @@ __device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const u
         if (!single(tp, ls, ll, ml, off, tok)) return false;
         si = p;
     }
-    return true;
+    return drain(true);
 }

@@ -45,7 +45,7 @@ __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t r
     if (r >= nreg) return;
     RgRegion R;
     R.b = r * rs; R.entry = R.b; R.exit = RG_INVALID; R.outlen = 0; R.entry0 = R.b; R.exit0 = RG_INVALID; R.outlen0 = 0; R.ntrace = 0;
-    R.needfull = 1; R.pad0 = 0; R.opos = 0; R.pad1[0] = R.pad1[1] = R.pad1[2] = R.pad1[3] = 0;
+    R.needfull = 1; R.pad0 = R.b; R.opos = 0; R.pad1[0] = R.pad1[1] = R.pad1[2] = R.pad1[3] = 0;
     reg[r] = R;
 }
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
             const uint32_t ex = invalid ? RG_INVALID : exitp;
             R->exit = ex; R->outlen = (uint32_t)out;
             R->entry0 = start; R->exit0 = ex; R->outlen0 = (uint32_t)out; R->ntrace = ntok < RG_DENSE ? ntok : RG_DENSE;
-            R->needfull = 0;
+            R->needfull = 0; R->pad0 = start;                            // the whole trace lies on this parse
         }
         wave_sync();
     }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
                         uint32_t cum0 = RG_INVALID;
                         if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
                         else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
-                        if (cum0 != RG_INVALID) { s_exit[r] = exit0; s_outl[r] = (uint32_t)(cum + (outlen0 - cum0)); s_need[r] = 0; settled = true; break; }
+                        if (cum0 != RG_INVALID) { s_exit[r] = exit0; s_outl[r] = (uint32_t)(cum + (outlen0 - cum0)); s_need[r] = 0; reg[r].pad0 = (uint32_t)p; settled = true; break; }
                         // one token, serially
                         const uint32_t tok = src[p];
                         uint64_t q = p + 1, ll = tok >> 4;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_rg_fix(const uint8_t *__restrict__ src, 
         uint32_t cum0 = RG_INVALID;
         if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
         else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
-        if (cum0 != RG_INVALID) { R->exit = exit0; R->outlen = (uint32_t)(cum + (outlen0 - cum0)); R->needfull = 0; return; }
+        if (cum0 != RG_INVALID) { R->exit = exit0; R->outlen = (uint32_t)(cum + (outlen0 - cum0)); R->needfull = 0; R->pad0 = (uint32_t)p; return; }
         const uint32_t tok = src[p];
         uint64_t q = p + 1, ll = tok >> 4;
         bool bad = false;
