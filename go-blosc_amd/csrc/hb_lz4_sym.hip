@@ -22,7 +22,6 @@
 // then decodes and reports what lz4.UncompressBlock reports.  A block that passes is decoded to exactly the bytes the serial
 // decoder produces -- every output byte is written from the same source by the same rule, only in a different order.
 #include "hb_lz4_region.h"
-#include <cstdlib>
 
 #define SY_W        65536u        // entries of a tail map / bytes of a tail image (index = distance 1..65535; entry 0 unused)
 #define SY_GROUPS   128u          // groups of regions in pass B
@@ -38,7 +37,7 @@
 
 struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact; uint32_t pad[9]; };   // per: units WITH OUTPUT per group of pass B
 // what one wavefront of pass A decodes: a region of the token discovery, or one of SY_SUB parts of a region whose output is large
-struct SyUnit { uint32_t entry, exit, opos, outlen, rtp, rout, state, ticks; };   // state: bit 0 done, bit 1 / 2: literals / match of token rtp copied
+struct SyUnit { uint32_t entry, exit, opos, outlen, rtp, rout, state, pad; };   // state: bit 0 done, bit 1 / 2: literals / match of token rtp copied
 struct SyBig { uint32_t kind, dst, src, len, O, pad[3]; };          // kind 0: literals from stream position src; 1: match, src = offset
 struct SyLayout { size_t plan, par, units, list, big, items, sym, maps, tails, total; };
 static inline uint32_t sy_max_groups(size_t n_out) {
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(64) void k_sy_units(const RgPlan *rg, const RgRegio
         if ((uint32_t)lane < SY_SUB) {
             SyUnit x;
             x.entry = s_e[lane]; x.exit = s_e[lane + 1]; x.opos = s_o[lane]; x.outlen = s_o[lane + 1] - s_o[lane];
-            x.rtp = 0; x.rout = 0; x.state = 0; x.ticks = 0;
+            x.rtp = 0; x.rout = 0; x.state = 0; x.pad = 0;
             u[lane] = x;
         }
     }
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_sy_compact(SyPlan *sy, const SyUnit *_
 // Unit state between launches (SyUnit): rtp = stream position of the token to resume at (0: not started), rout = output position
 // there, state bit 0 = unit done, bit 1 = that token's literals are copied, bit 2 = its match too.
 __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ src, uint64_t n_src, SyUnit *un, const uint32_t *__restrict__ list,
-                                                   SyPlan *sy, SyBig *big, uint8_t *D, uint16_t *S, int last, int dbg) {
+                                                   SyPlan *sy, SyBig *big, uint8_t *D, uint16_t *S, int last) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     __shared__ __attribute__((aligned(16))) uint8_t s_d[SY_IMG + 64];
@@ -374,7 +373,6 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
         auto flush = [&]() __attribute__((always_inline)) {
             const uint32_t n = out - fl;
             if (n == 0u) return;
-            if (dbg & 8) { fl = out; return; }
             wave_sync();
             const uint32_t o = fl - ib;
             const uint8_t *s_sb = (const uint8_t *)s_s;
@@ -444,8 +442,7 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
                 const bool act = tok && (uint32_t)lane >= lo && (uint32_t)lane < hi;
                 const uint32_t t0 = d0 - ib, tm = md - ib;
                 // literals: from the staged stream window
-                if (dbg & 16) { out = hi == cnt ? end_all : __builtin_amdgcn_readlane(d0, (int)hi); lo = hi; continue; }
-                if (act && lit <= 32u && !(dbg & 4)) sy_lits_img_lane(s_d, s_s, t0, s_win + lp, lit);
+                if (act && lit <= 32u) sy_lits_img_lane(s_d, s_s, t0, s_win + lp, lit);
                 unsigned long long lm = hb_ballot(act && lit > 32u);
                 while (lm) {
                     const int l = __builtin_ctzll(lm);
@@ -455,7 +452,7 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
                 // the part of every match whose source lies in front of the image: from HBM, all lanes at once (nothing in the batch can
                 // change those bytes)
                 const uint32_t farlen = (act && s0 < ib) ? (ib - s0 < mlen ? ib - s0 : mlen) : 0u;
-                if (hb_ballot(farlen != 0u) && !(dbg & 2)) {
+                if (hb_ballot(farlen != 0u)) {
                     if (unsynced) { sy_sync(); unsynced = false; }
                     sy_fetch_lane(D, S, s_d, s_s, tm, s0, farlen <= thr ? farlen : 0u, O);
                     lm = hb_ballot(farlen > thr);
@@ -470,7 +467,7 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
                 // pending match in front of it)
                 const uint32_t nlen = act ? mlen - farlen : 0u, nmd = tm + farlen;
                 const uint32_t srcs = nmd - off, srcend = srcs + (nlen < off ? nlen : off), mend = nmd + nlen;
-                unsigned long long pend = (dbg & 1) ? 0ull : hb_ballot(nlen != 0u);
+                unsigned long long pend = hb_ballot(nlen != 0u);
                 while (pend) {
                     const int f = __builtin_ctzll(pend);
                     const uint32_t X = __builtin_amdgcn_readlane(nmd, f);
@@ -614,18 +611,28 @@ __global__ __launch_bounds__(1024) void k_sy_chain(const SyPlan *sy, const uint3
     u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
     for (int q = 0; q < 4; q++) ((u32x4 *)s_f)[t * 4 + q] = z;         // nothing in front of the block (never referenced: pass A checked)
     __syncthreads();
+    // the map of group g is fetched while the tail in front of group g is still being written (the maps are all there: k_sy_compose is done)
+    u32x4 e[16];
+    if (G > 1u) {
+        const u32x4 *m = (const u32x4 *)(maps + ((size_t)0 * 2 + par[0]) * SY_W) + (size_t)t * 16;
+#pragma unroll
+        for (int q = 0; q < 16; q++) e[q] = m[q];
+    }
     for (uint32_t g = 0; g < G; g++) {
-        u32x4 o[4];
-        for (int q = 0; q < 4; q++) { o[q] = ((const u32x4 *)s_f)[t * 4 + q]; ((u32x4 *)(tails + (size_t)g * SY_W))[t * 4 + q] = o[q]; }
+        for (int q = 0; q < 4; q++) ((u32x4 *)(tails + (size_t)g * SY_W))[t * 4 + q] = ((const u32x4 *)s_f)[t * 4 + q];
         if (g + 1 == G) break;
-        const u32x4 *m = (const u32x4 *)(maps + ((size_t)g * 2 + par[g]) * SY_W) + (size_t)t * 16;
         uint32_t w[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const u32x4 e = m[q];
-            const uint32_t b0 = (e.x >> 16) ? s_f[e.x >> 16] : (e.x & 255u), b1 = (e.y >> 16) ? s_f[e.y >> 16] : (e.y & 255u);
-            const uint32_t b2 = (e.z >> 16) ? s_f[e.z >> 16] : (e.z & 255u), b3 = (e.w >> 16) ? s_f[e.w >> 16] : (e.w & 255u);
+            const u32x4 x = e[q];
+            const uint32_t b0 = (x.x >> 16) ? s_f[x.x >> 16] : (x.x & 255u), b1 = (x.y >> 16) ? s_f[x.y >> 16] : (x.y & 255u);
+            const uint32_t b2 = (x.z >> 16) ? s_f[x.z >> 16] : (x.z & 255u), b3 = (x.w >> 16) ? s_f[x.w >> 16] : (x.w & 255u);
             w[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+        if (g + 2 < G) {
+            const u32x4 *m = (const u32x4 *)(maps + ((size_t)(g + 1) * 2 + par[g + 1]) * SY_W) + (size_t)t * 16;
+#pragma unroll
+            for (int q = 0; q < 16; q++) e[q] = m[q];
         }
         __syncthreads();
 #pragma unroll
@@ -796,7 +803,6 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     SyUnit *un = (SyUnit *)(sym_work + L.units);
     SyBig *big = (SyBig *)(sym_work + L.big);
     uint32_t *list = (uint32_t *)(sym_work + L.list);
-    static const int dbg = getenv("HIPBLOSC_SY_DBG") ? atoi(getenv("HIPBLOSC_SY_DBG")) : 0;
     hb_prof_begin("k_sy_units", s);
     hipLaunchKernelGGL(k_sy_gate, dim3(1), dim3(1), 0, s, rg, dp, sy, groups, per);
     hipLaunchKernelGGL(k_sy_units, dim3((nreg + 3) / 4), dim3(64), 0, s, rg, reg, (const uint2 *)(w + RL.trace), sy, un);
@@ -805,7 +811,7 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     for (int k = 0; k < SY_ROUNDS; k++) {
         const int last = k + 1 == SY_ROUNDS;
         hb_prof_begin("k_sy_decode", s);
-        hipLaunchKernelGGL(k_sy_decode, dim3(nunits < 4096u ? nunits : 4096u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last, dbg);
+        hipLaunchKernelGGL(k_sy_decode, dim3(nunits < 4096u ? nunits : 4096u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last);
         hb_prof_end(s);
         if (!last) {
             hb_prof_begin("k_sy_big", s);

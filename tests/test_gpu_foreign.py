@@ -3,9 +3,10 @@
 Two kinds exist.  (1) Frames this library writes without HB_OPT_INDEX_TRAILER (the drop-in default: a reference frame ends at
 NBytesComp): their matches never leave a 4 KiB chunk, so the device rebuilds the index from the stream (guess-and-verify token
 discovery, csrc/hb_lz4_region.hip) and decodes chunk-parallel.  (2) Frames the REFERENCE writes (one LZ4 block, 64 KiB window,
-codec.go:63-75 -- here: the oracle's restatement of lz4.CompressBlock, and liblz4 as a second foreign parse): the rebuilt index
-cannot hold for them (matches cross every chunk boundary), the single wavefront decodes; what matters is that the attempt never
-changes a byte or an error.  Expected bytes: the oracle decoder's (the restated reference `Decompress`).
+codec.go:63-75 -- here: the oracle's restatement of lz4.CompressBlock, and liblz4 as a second foreign parse): no index can hold
+for them (matches cross every chunk boundary); they are decoded in parallel from the verified token chain, symbolically
+(csrc/hb_lz4_sym.hip), when the caller's workspace has room for it, and by one wavefront otherwise.  Whatever path runs, bytes and
+errors must be the oracle decoder's (the restated reference `Decompress`).
 """
 import ctypes
 import os
@@ -52,12 +53,73 @@ def _cases(O):
     return out
 
 
+def _many_big_runs(rng):
+    # more runs of SY_BIG bytes and above in ONE region of the stream than pass A has launches to park them in (the last launch
+    # copies inline), separated by a few literals, then enough random bytes for the payload to qualify for the region path
+    parts = []
+    for k in range(12):
+        parts.append(np.full((300 << 10) + 17 * k, k + 1, np.uint8))
+        parts.append(rng.integers(0, 256, 5 + k, dtype=np.uint8))
+    parts.append(np.tile(np.arange(7, dtype=np.uint8), 100000))            # one long match with period 7
+    parts.append(rng.integers(0, 256, (1 << 20) + 3, dtype=np.uint8))
+    parts.append(np.zeros((5 << 20) + 1, np.uint8))
+    return np.concatenate(parts)
+
+
 def test_reference_shaped_frames_decode_exactly(hb, O):
-    for name, (x, shuffle, ts, _) in _cases(O).items():
+    cases = _cases(O)
+    cases["many_big_runs"] = (_many_big_runs(np.random.default_rng(4)), 0, 1, None)
+    parallel = {}
+    for name, (x, shuffle, ts, _) in cases.items():
         f = O.compress_frame(x, shuffle=shuffle, typesize=ts)
         want = O.decompress_frame(f)
         assert np.array_equal(want, x.view(np.uint8).reshape(-1))
         assert hb.Decompress(f.tobytes()) == x.tobytes(), name
+        parallel[name] = bool(hb.lib().hb_last_result_flags() & 1)
+    # the symbolic decoder took every frame whose payload is large enough for the region path (256 KiB)
+    for name in ("f32_24MiB_shuffle", "f64_16MiB_shuffle8", "i32_16MiB_bitshuffle", "few_valued_12MiB", "rand_then_zeros_then_text",
+                 "far_offsets", "many_big_runs"):
+        assert parallel[name], (name, parallel)
+
+
+def test_foreign_frames_need_the_larger_workspace(hb, O):
+    # device-pointer API: with hb_decompress_frame_workspace() a reference-shaped frame goes to the single wavefront, with
+    # hb_decompress_frame_workspace_foreign() to the symbolic decoder; same bytes.  (Device buffers through the HIP runtime the
+    # library itself is linked to -- a second runtime in the process, e.g. torch's, would not see the GPU.)
+    L = hb.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    H2D, D2H = 1, 2
+
+    def dmalloc(nb):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), nb) == 0
+        return ptr
+
+    x = O.synth(O.D_F32, (8 << 20) // 4)
+    f = O.compress_frame(x, shuffle=1, typesize=4)
+    n = x.nbytes
+    small, large = L.hb_decompress_frame_workspace(n), L.hb_decompress_frame_workspace_foreign(n)
+    assert large > small + 2 * n
+    d_frame, d_out, d_res, d_work = dmalloc(f.size + 64), dmalloc(n), dmalloc(64), dmalloc(large)
+    try:
+        assert hip.hipMemcpy(d_frame, f.ctypes.data, f.size, H2D) == 0
+        for wb, want_flag in ((small, 0), (large, 1)):
+            assert hip.hipMemset(d_out, 0, n) == 0
+            rc = L.hb_decompress_frame_dev(d_frame, f.size, d_out, n, 0, d_work, wb, d_res, None)
+            assert rc == 0 and hip.hipDeviceSynchronize() == 0
+            res = np.zeros(32, np.uint8)
+            back = np.empty(n, np.uint8)
+            assert hip.hipMemcpy(res.ctypes.data, d_res, 32, D2H) == 0 and hip.hipMemcpy(back.ctypes.data, d_out, n, D2H) == 0
+            assert int(res[:4].view(np.int32)[0]) == 0
+            assert int(res[4:8].view(np.uint32)[0]) & 1 == want_flag
+            assert np.array_equal(back, x)
+    finally:
+        for ptr in (d_frame, d_out, d_res, d_work):
+            hip.hipFree(ptr)
 
 
 def test_own_frames_without_the_trailer_decode_in_parallel(hb, O):
@@ -163,5 +225,10 @@ def test_index_less_frames_at_full_size(hb, O):
     print(f"index-less 1 GiB frame host->host: {n / dt / 1e9:.2f} GB/s")
     m = 256 << 20
     f = O.compress_frame(x[:m], shuffle=1, typesize=4)
+    back[:m] = 0
+    t0 = time.perf_counter()
     assert L.hb_decompress_frame(f.ctypes.data, f.size, back.ctypes.data, m, 0, 0) == m
+    dt = time.perf_counter() - t0
+    assert L.hb_last_result_flags() & 1, "the reference-shaped frame was not decoded in parallel"
     assert np.array_equal(back[:m], x[:m]), "reference-shaped frame: device decode differs"
+    print(f"reference-shaped 256 MiB frame host->host: {m / dt / 1e9:.2f} GB/s")

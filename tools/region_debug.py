@@ -75,18 +75,6 @@ def main():
     b, entry, exit_, outlen, entry0, exit0, outlen0, ntrace, needfull = [regs[:, i] for i in range(9)]
     print("needfull", int(needfull.sum()), "invalid exits", int((exit_ == 0xFFFFFFFF).sum()), "entry!=prev exit", int((entry[1:] != exit_[:-1]).sum()),
           "entry moved from guess", int((entry != b).sum()), "empty regions", int((outlen == 0).sum()))
-    if not a.small_work and os.environ.get("HIPBLOSC_SY_DBG") and int(os.environ["HIPBLOSC_SY_DBG"]) & 64:
-        # SyUnit array of the symbolic decoder (hb_lz4_sym.hip: sy_layout): behind SyPlan (256 B) and the group parities (512 B)
-        sbase = ((L.hb_decompress_frame_workspace(n) + 255) & ~255) + 768
-        un = w[sbase: sbase + nreg * 8 * 32].view(np.uint32).reshape(nreg * 8, 8)
-        ticks = un[:, 7].astype(np.int64)
-        act = un[:, 3] > 0
-        print("units with output:", int(act.sum()), "of", un.shape[0], "; heavy regions:", int((outlen > (1 << 20)).sum()))
-        order = np.argsort(-ticks)[:10]
-        print("slowest units of pass A (100 MHz clock):")
-        for i in order:
-            print(f"   unit {i} (region {i // 8}): {ticks[i] / 100:.1f} us, outlen {un[i, 3]}, stream {un[i, 1] - un[i, 0]}, opos {un[i, 2]}")
-        print("   histogram ms:", np.histogram(ticks[act] / 1e5, bins=[0, 0.25, 0.5, 1, 2, 4, 8, 16, 32, 64])[0].tolist(), "sum ms", ticks.sum() / 1e5)
     bad = np.nonzero(entry[1:] != exit_[:-1])[0][:8]
     for i in bad:
         print("  region", i + 1, "b", b[i + 1], "entry", entry[i + 1], "prev exit", exit_[i], "exit", exit_[i + 1], "needfull", needfull[i + 1])
