@@ -48,10 +48,14 @@ __device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, 
     while (nq < 64u && !stop) {
         if (si == lim) { stop = true; break; }
         const uint32_t base = si, p = base + (uint32_t)lane;
-        const uint32_t t = p < lim ? (uint32_t)s_in[sh + p] : 0u;
-        bool cplx = p >= lim;
+        // token + the first three bytes of a literal-length extension in one read; offset + the first two bytes of a match-length
+        // extension in a second one: lengths up to 15 + 3 * 255 / 19 + 2 * 255 take no further LDS round trip (the staged window has
+        // slack behind `lim`; what is read there is only used when the position checks below pass)
+        const uint32_t w = dec_read4(s_in, sh + p);
+        const uint32_t t = w & 255u;
+        bool cplx = p + 4u > lim;
         uint32_t lit = t >> 4, q = p + 1u;
-        // a length extension, four bytes per step (a lane that sits inside a run of 0xFF -- every byte of a long extension looks like
+        // a longer extension, four bytes per step (a lane that sits inside a run of 0xFF -- every byte of a long extension looks like
         // the start of another one -- gives up after 24 bytes instead of crawling through it)
         auto ext = [&](uint32_t &len, uint32_t &at) __attribute__((always_inline)) {
             bool open = true;
@@ -68,11 +72,26 @@ __device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, 
             }
             return !open;
         };
-        if (lit == 15u && !ext(lit, q)) cplx = true;
+        bool longl = false;
+        if (lit == 15u) {
+            const uint32_t e = ~(w >> 8) & 0xFFFFFFu;                     // a zero byte where the extension byte is 255
+            if (e) {
+                const uint32_t nff = (uint32_t)__builtin_ctz(e) >> 3;     // extension bytes that are 255
+                lit = 15u + 255u * nff + ((w >> (8u * (nff + 1u))) & 255u);
+                q = p + 2u + nff;
+            } else { lit = 15u + 765u; q = p + 4u; longl = true; }
+        }
+        if (longl && !cplx && !ext(lit, q)) cplx = true;
         const uint32_t nbl = q - p - 1u, offpos = q + lit;
         uint32_t mlen = 4u + (t & 15u), q2 = offpos + 2u;
-        if (cplx || offpos + 3u > lim) cplx = true;              // literal-only tail, or too close to the edge
-        else if ((t & 15u) == 15u && !ext(mlen, q2)) cplx = true;
+        if (cplx || offpos + 4u > lim) cplx = true;              // literal-only tail, or too close to the edge
+        else if ((t & 15u) == 15u) {
+            const uint32_t x = dec_read4(s_in, sh + offpos);
+            const uint32_t e1 = (x >> 16) & 255u, e2 = x >> 24;
+            if (e1 != 255u) { mlen = 19u + e1; q2 = offpos + 3u; }
+            else if (e2 != 255u) { mlen = 19u + 255u + e2; q2 = offpos + 4u; }
+            else { mlen = 19u + 510u; q2 = offpos + 4u; if (!ext(mlen, q2)) cplx = true; }
+        }
         if (lit > 0xFFFFu || mlen > 0xFFFFu) cplx = true;
         const uint32_t nxt = q2;
         const unsigned long long cmask = hb_ballot(cplx);

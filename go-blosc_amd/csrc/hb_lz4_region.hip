@@ -63,10 +63,19 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
         const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)RFL(reg[r + 1].b) : n_src;
         uint2 *tr = traces + (size_t)r * RG_TRACE;
         const uint32_t rb = RFL(R->b), bsh = plan->pad[0];                 // bucket = (position - b) >> bsh
-        for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
+        // A region that was parsed before (from a wrong first token) is first re-parsed in MERGE mode: nothing is recorded, the first
+        // token of every bucket is compared with the one on record, and at the first match the two parses have merged -- exit
+        // unchanged, output length corrected by the difference -- typically a few hundred tokens in instead of the whole region.
+        // Only a parse that reaches the end of the region without meeting the old one is repeated in recording mode.
+        const bool can_merge = !first && RFL(R->exit0) != RG_INVALID;
+        const uint32_t exit0 = RFL(R->exit0), outlen0 = RFL(R->outlen0);
+      for (int pass = 0; pass < 2; pass++) {
+        const bool mm = can_merge && pass == 0;
+        if (!mm) for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
         uint64_t si = start, wpos = 0, out = 0;
         uint32_t wlen = 0, wsh = 0, nq = 0, ntok = 0, exitp = RG_INVALID, lastbk = RG_INVALID;
-        bool invalid = false;
+        bool invalid = false, merged = false;
+        uint32_t mpos = 0, mcum = 0, mc0 = 0;
         auto refill = [&](uint64_t at) __attribute__((always_inline)) {
             const uint8_t *g = src + at;
             wsh = (uint32_t)((uintptr_t)g & 15u);
@@ -99,7 +108,19 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
                 // trace: the first RG_DENSE tokens, and the first token that starts in each bucket of the region's stream range
                 const uint32_t bk = (uint32_t)lane < cnt ? ((uint32_t)ap - rb) >> bsh : RG_INVALID;
                 const uint32_t pbk = wave_shr1(bk, lastbk);
-                if ((uint32_t)lane < cnt) {
+                if (mm) {
+                    bool hit = false; uint32_t c0 = 0;
+                    if ((uint32_t)lane < cnt && bk != pbk && bk < RG_BUCKETS) { const uint2 o = tr[RG_DENSE + bk]; hit = o.x == (uint32_t)ap; c0 = o.y; }
+                    const unsigned long long hm = hb_ballot(hit);
+                    if (hm) {
+                        const int j = __builtin_ctzll(hm);
+                        mpos = RFL(__builtin_amdgcn_readlane((uint32_t)ap, j));
+                        mcum = (uint32_t)out + (uint32_t)__builtin_amdgcn_readlane(incl - olen, j);
+                        mc0 = (uint32_t)__builtin_amdgcn_readlane(c0, j);
+                        merged = true; done = true; nq = 0;
+                        break;
+                    }
+                } else if ((uint32_t)lane < cnt) {
                     uint2 t; t.x = (uint32_t)ap; t.y = (uint32_t)(out + incl - olen);
                     if (idx < RG_DENSE) tr[idx] = t;
                     if (bk != pbk && bk < RG_BUCKETS) tr[RG_DENSE + bk] = t;
@@ -147,7 +168,12 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
             }
             {
                 const uint32_t bk = (tokstart - rb) >> bsh;
-                if (lane == 0) {
+                if (mm) {
+                    if (bk != lastbk && bk < RG_BUCKETS) {
+                        const uint32_t ox = RFL(tr[RG_DENSE + bk].x), oy = RFL(tr[RG_DENSE + bk].y);
+                        if (ox == tokstart) { mpos = tokstart; mcum = (uint32_t)out; mc0 = oy; merged = true; break; }
+                    }
+                } else if (lane == 0) {
                     uint2 t; t.x = tokstart; t.y = (uint32_t)out;
                     if (ntok < RG_DENSE) tr[ntok] = t;
                     if (bk != lastbk && bk < RG_BUCKETS) tr[RG_DENSE + bk] = t;
@@ -160,12 +186,19 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
             if (out > 0xFFFFFFF0ull) { invalid = true; break; }
         }
         if (out > 0xFFFFFFF0ull) invalid = true;
+        if (merged) {
+            if (lane == 0) { R->exit = exit0; R->outlen = mcum + (outlen0 - mc0); R->needfull = 0; R->pad0 = mpos; }
+            break;
+        }
+        if (mm && !invalid) { wave_sync(); continue; }                  // never met the old parse: once more, recording
         if (lane == 0) {
             const uint32_t ex = invalid ? RG_INVALID : exitp;
             R->exit = ex; R->outlen = (uint32_t)out;
             R->entry0 = start; R->exit0 = ex; R->outlen0 = (uint32_t)out; R->ntrace = ntok < RG_DENSE ? ntok : RG_DENSE;
             R->needfull = 0; R->pad0 = start;                            // the whole trace lies on this parse
         }
+        break;
+      }
         wave_sync();
     }
 }
