@@ -11,7 +11,8 @@
 #define RG_MAXREG   4096u
 #define RG_MINREG   65536u        // smallest region, stream bytes
 #define RG_PWIN     8192u         // parse window
-#define RG_FIXROUNDS 4             // k_rg_settle launches (each iterates to a standstill), full parses in between
+#define RG_FIXROUNDS 32            // k_rg_settle launches (each iterates to a standstill; idle once settled), re-parses in between
+#define RG_WALKCAP   32            // tokens a lane walks serially (3 us each) before it asks for a wave-parallel re-parse (70 ns each)
 
 struct __attribute__((aligned(16))) RgRegion {
     uint32_t b;          // nominal start (stream position)

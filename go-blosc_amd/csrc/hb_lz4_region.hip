@@ -37,7 +37,7 @@ bool hb_lz4_region_wanted(const hb_dec_args &a) { return !a.index && !a.memcpy_p
 __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r == 0) {
-        plan->pad[1] = 0;
+        plan->pad[1] = 0; plan->pad[2] = 0;
         plan->ok = 0; plan->fail = 0; plan->nreg = nreg; plan->rs = rs; plan->total = 0;
         uint32_t sh = 0; while (((uint64_t)RG_BUCKETS << sh) < rs) sh++;      // RG_BUCKETS << sh >= rs: every position of a region has a bucket
         plan->pad[0] = sh;
@@ -63,14 +63,15 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
         const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)RFL(reg[r + 1].b) : n_src;
         uint2 *tr = traces + (size_t)r * RG_TRACE;
         const uint32_t rb = RFL(R->b), bsh = plan->pad[0];                 // bucket = (position - b) >> bsh
-        // A region that was parsed before (from a wrong first token) is first re-parsed in MERGE mode: nothing is recorded, the first
-        // token of every bucket is compared with the one on record, and at the first match the two parses have merged -- exit
-        // unchanged, output length corrected by the difference -- typically a few hundred tokens in instead of the whole region.
-        // Only a parse that reaches the end of the region without meeting the old one is repeated in recording mode.
-        const bool can_merge = !first && RFL(R->exit0) != RG_INVALID;
+        // A region that was parsed before is re-parsed in MERGE mode: nothing is recorded, the first token of every bucket is compared
+        // with the one on record, and at the first match the two parses have merged -- exit unchanged, output length corrected by the
+        // difference -- typically a few hundred tokens in instead of the whole region.  A parse that never meets the recorded one
+        // just delivers its exit and output length; the record stays what the region's FIRST parse left: that one started at
+        // the region's first byte and has, as a rule, fallen onto the true chain, while a later first token may come from a stray
+        // parse further up (in periodic data stray and true chains run side by side and never meet: a record overwritten by a
+        // stray parse would make the correction that follows one region behind pay a full parse per region too).
+        const bool mm = !first && RFL(R->exit0) != RG_INVALID;
         const uint32_t exit0 = RFL(R->exit0), outlen0 = RFL(R->outlen0);
-      for (int pass = 0; pass < 2; pass++) {
-        const bool mm = can_merge && pass == 0;
         if (!mm) for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
         uint64_t si = start, wpos = 0, out = 0;
         uint32_t wlen = 0, wsh = 0, nq = 0, ntok = 0, exitp = RG_INVALID, lastbk = RG_INVALID;
@@ -186,19 +187,17 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
             if (out > 0xFFFFFFF0ull) { invalid = true; break; }
         }
         if (out > 0xFFFFFFF0ull) invalid = true;
-        if (merged) {
-            if (lane == 0) { R->exit = exit0; R->outlen = mcum + (outlen0 - mc0); R->needfull = 0; R->pad0 = mpos; }
-            break;
-        }
-        if (mm && !invalid) { wave_sync(); continue; }                  // never met the old parse: once more, recording
         if (lane == 0) {
             const uint32_t ex = invalid ? RG_INVALID : exitp;
-            R->exit = ex; R->outlen = (uint32_t)out;
-            R->entry0 = start; R->exit0 = ex; R->outlen0 = (uint32_t)out; R->ntrace = ntok < RG_DENSE ? ntok : RG_DENSE;
-            R->needfull = 0; R->pad0 = start;                            // the whole trace lies on this parse
+            if (merged) { R->exit = exit0; R->outlen = mcum + (outlen0 - mc0); R->pad0 = mpos; }
+            else if (mm) { R->exit = ex; R->outlen = (uint32_t)out; R->pad0 = RG_INVALID; }       // (nothing on record lies on this chain)
+            else {
+                R->exit = ex; R->outlen = (uint32_t)out;
+                R->entry0 = start; R->exit0 = ex; R->outlen0 = (uint32_t)out; R->ntrace = ntok < RG_DENSE ? ntok : RG_DENSE;
+                R->pad0 = start;                                         // the whole record lies on this parse
+            }
+            R->needfull = 0;
         }
-        break;
-      }
         wave_sync();
     }
 }
@@ -209,13 +208,14 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
 // of the regions inside such a run (they started at bytes that are literals) are out-voted as long as they stay local.  A region
 // whose belief changed re-parses from the new entry one token at a time until it lands on a position of its recorded trace (the
 // parses have merged: exit unchanged, output length corrected by the difference) or asks for a full parse.  One workgroup, the
-// regions' state in LDS, iterated until nothing moves or a full parse is pending. ----
+// regions' state in LDS, iterated until nothing moves. ----
 __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces) {
     __shared__ uint32_t s_entry[RG_MAXREG], s_exit[RG_MAXREG], s_outl[RG_MAXREG], s_need[RG_MAXREG];
     __shared__ uint32_t s_pm[1024];
     __shared__ uint32_t s_changed, s_pend;
     const int t = threadIdx.x;
     const uint32_t nreg = plan->nreg, bsh = plan->pad[0];
+    if (plan->pad[2]) return;                                           // an earlier launch came to a standstill with nothing pending
     constexpr uint32_t PER = RG_MAXREG / 1024;
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t r = (uint32_t)t * PER + k;
@@ -223,9 +223,12 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
     }
     if (t == 0) { s_changed = 0; s_pend = 0; }
     __syncthreads();
+    bool capped = true;                                                 // left the loop because of the iteration cap, still moving
     for (int it = 0; it < 48; it++) {
         uint32_t mx = 0;
-        for (uint32_t k = 0; k < PER; k++) { const uint32_t r = (uint32_t)t * PER + k; if (r < nreg && s_exit[r] != RG_INVALID) mx = max(mx, s_exit[r]); }
+        // (a region without a token of its own -- exit == entry -- has nothing to say: if it repeated the position it was handed, a wrong
+        // one would outlive its source, the stray parse of a region inside a long literal run, by one region per iteration)
+        for (uint32_t k = 0; k < PER; k++) { const uint32_t r = (uint32_t)t * PER + k; if (r < nreg && s_exit[r] != RG_INVALID && s_exit[r] != s_entry[r]) mx = max(mx, s_exit[r]); }
         s_pm[t] = mx;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
                     uint64_t p = a, cum = 0;
                     uint32_t ti = 0;
                     bool settled = false;
-                    for (int iter = 0; iter < 96 && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a full, wave-parallel parse)
+                    for (int iter = 0; iter < RG_WALKCAP && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a wave-parallel re-parse)
                         if (p >= bnext) { s_exit[r] = (uint32_t)p; s_outl[r] = (uint32_t)cum; s_need[r] = 0; settled = true; break; }
                         // merged with the recorded parse?  (one of its first tokens, or the first token of a bucket: once the parses have
                         // merged, this walk visits every token of the recorded one, so it meets a recorded position within a bucket)
@@ -282,20 +285,20 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
                     if (!settled) { s_exit[r] = RG_INVALID; s_need[r] = 1; s_pend = 1; }     // k_rg_parse takes it from `entry`
                 }
             }
-            if (s_exit[r] != RG_INVALID) run = max(run, s_exit[r]);
+            if (s_exit[r] != RG_INVALID && s_exit[r] != s_entry[r]) run = max(run, s_exit[r]);
         }
         __syncthreads();
-        const bool go = s_changed && !s_pend;
+        const bool go = s_changed != 0u;                                // (regions waiting for a re-parse sit out; the others go on)
         __syncthreads();
         if (t == 0) s_changed = 0;
         __syncthreads();
-        if (!go) break;
+        if (!go) { capped = false; break; }
     }
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t r = (uint32_t)t * PER + k;
         if (r < nreg) { reg[r].entry = s_entry[r]; reg[r].exit = s_exit[r]; reg[r].outlen = s_outl[r]; reg[r].needfull = s_need[r]; }
     }
-    if (t == 0) plan->pad[1] = s_pend;                                  // full parses pending: the next k_rg_parse has work
+    if (t == 0) { plan->pad[1] = s_pend; if (!s_pend && !capped) plan->pad[2] = 1; }   // parses pending: the next k_rg_parse has work; else: settled
 }
 
 // the first round of (1b) has nearly every region re-walk its head: one lane per region over the whole chip instead of one workgroup
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(1024) void k_rg_pmax(RgPlan *plan, const RgRegion *
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t r = (uint32_t)t * PER + k;
         uint32_t e = 0;
-        if (r < nreg) { e = reg[r].exit; if (e == RG_INVALID) e = 0; }
+        if (r < nreg) { e = reg[r].exit; if (e == RG_INVALID || e == reg[r].entry) e = 0; }
         mine[k] = e;
         mx = max(mx, e);
     }
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(64) void k_rg_fix(const uint8_t *__restrict__ src, 
     const uint32_t nt = R->ntrace, exit0 = R->exit0, outlen0 = R->outlen0;
     uint64_t p = a, cum = 0;
     uint32_t ti = 0;
-    for (int iter = 0; iter < 96 && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a full, wave-parallel parse)
+    for (int iter = 0; iter < RG_WALKCAP && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a wave-parallel re-parse)
         if (p >= bnext) { R->exit = (uint32_t)p; R->outlen = (uint32_t)cum; R->needfull = 0; return; }
         while (ti < nt && tr[ti].x < (uint32_t)p) ti++;
         uint32_t cum0 = RG_INVALID;
@@ -568,7 +571,7 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     hb_prof_begin("k_rg_settle", s);
     for (int k = 0; k < RG_FIXROUNDS; k++) {
         hipLaunchKernelGGL(k_rg_settle, dim3(1), dim3(1024), 0, s, a.src, (uint64_t)a.n, plan, reg, traces);
-        if (k + 1 < RG_FIXROUNDS)                                       // regions that asked for a full parse (returns at once when none did)
+        if (k + 1 < RG_FIXROUNDS)                                       // regions that asked for a re-parse (returns at once when none did)
             hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
     }
     hipLaunchKernelGGL(k_rg_scan, dim3(1), dim3(1024), 0, s, plan, reg, (uint64_t)a.n, (uint64_t)a.cap);

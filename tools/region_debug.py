@@ -34,6 +34,7 @@ def main():
                     help="oracle: the restated reference encoder (64 KiB window); device: this library WITHOUT the index trailer")
     ap.add_argument("--small-work", action="store_true", help="workspace without the symbolic decoder's scratch (foreign frames then decode on one wavefront)")
     ap.add_argument("--reps", type=int, default=1)
+    ap.add_argument("--dump", default="", help="lo:hi -- print the final state of these regions")
     a = ap.parse_args()
     L = hb.lib()
     assert L.hb_init() == 0
@@ -75,6 +76,12 @@ def main():
     b, entry, exit_, outlen, entry0, exit0, outlen0, ntrace, needfull = [regs[:, i] for i in range(9)]
     print("needfull", int(needfull.sum()), "invalid exits", int((exit_ == 0xFFFFFFFF).sum()), "entry!=prev exit", int((entry[1:] != exit_[:-1]).sum()),
           "entry moved from guess", int((entry != b).sum()), "empty regions", int((outlen == 0).sum()))
+    for i in np.nonzero((needfull != 0) | (exit_ == 0xFFFFFFFF))[0][:10]:
+        print(f"  pending r{i}: b {b[i]} entry {entry[i]} exit {exit_[i]} outlen {outlen[i]} | entry0 {entry0[i]} exit0 {exit0[i]} outlen0 {outlen0[i]} ntrace {ntrace[i]} needfull {needfull[i]} pad0 {regs[i, 9]}")
+    if a.dump:
+        lo, hi = (int(v) for v in a.dump.split(":"))
+        for i in range(lo, min(hi, nreg)):
+            print(f"  r{i}: b {b[i]} entry {entry[i]} exit {exit_[i]} outlen {outlen[i]} | entry0 {entry0[i]} exit0 {exit0[i]} outlen0 {outlen0[i]} ntrace {ntrace[i]} needfull {needfull[i]} pad0 {regs[i, 9]}")
     bad = np.nonzero(entry[1:] != exit_[:-1])[0][:8]
     for i in bad:
         print("  region", i + 1, "b", b[i + 1], "entry", entry[i + 1], "prev exit", exit_[i], "exit", exit_[i + 1], "needfull", needfull[i + 1])
