@@ -8,11 +8,14 @@
 #define RG_DENSE    128u
 #define RG_BUCKETS  128u
 #define RG_INVALID  0xFFFFFFFFu
-#define RG_MAXREG   4096u
+#define RG_MAXREG   8192u
 #define RG_MINREG   65536u        // smallest region, stream bytes
 #define RG_PWIN     8192u         // parse window
-#define RG_FIXROUNDS 32            // k_rg_settle launches (each iterates to a standstill; idle once settled), re-parses in between
-#define RG_WALKCAP   32            // tokens a lane walks serially (3 us each) before it asks for a wave-parallel re-parse (70 ns each)
+#define RG_FIXROUNDS 16            // k_rg_settle launches (each iterates to a standstill; idle once settled), re-parses in between
+#define RG_FPARSERS 2             // wavefronts of the last settle launch that parse (LDS: the regions' state takes 128 KiB)
+#define RG_FLIST    64            // regions it hands them per hop
+#define RG_MAXHOPS  1024          // hops it makes at most
+#define RG_WALKCAP   8             // tokens a lane walks serially (3 us each) before it asks for a wave-parallel re-parse (70 ns each)
 
 struct __attribute__((aligned(16))) RgRegion {
     uint32_t b;          // nominal start (stream position)
@@ -28,16 +31,20 @@ struct __attribute__((aligned(16))) RgRegion {
 struct RgPlan { uint32_t ok, fail, nreg, rs; uint64_t total; uint32_t pad[10]; };
 
 struct RgLayout { size_t plan, reg, pmax, trace, total; };
-static inline RgLayout rg_layout() {
+// sized for the regions a block that decodes to at most n_out bytes can have (a stream is never much longer than its output)
+static inline RgLayout rg_layout(size_t n_out) {
     RgLayout L; size_t o = 0;
     auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
+    size_t nr = (n_out + n_out / 255 + 16) / RG_MINREG + 2;
+    if (nr > RG_MAXREG) nr = RG_MAXREG;
     L.plan = take(sizeof(RgPlan));
-    L.reg = take((size_t)RG_MAXREG * sizeof(RgRegion));
-    L.pmax = take((size_t)RG_MAXREG * 4);
-    L.trace = take((size_t)RG_MAXREG * RG_TRACE * sizeof(uint2));
+    L.reg = take(nr * sizeof(RgRegion));
+    L.pmax = take(nr * 4);
+    L.trace = take(nr * RG_TRACE * sizeof(uint2));
     L.total = o;
     return L;
 }
+
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 // Window-parallel token parser for the passes that copy nothing.  Like dec_fill (hb_dec_common.h), but every lane also sums

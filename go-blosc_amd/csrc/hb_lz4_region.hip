@@ -30,9 +30,12 @@
 // plan->fail; k_dec_serial then decodes the block and reports what lz4.UncompressBlock would report.
 #include "hb_lz4_region.h"
 
-size_t hb_lz4_region_workspace(size_t n_out) { return rg_layout().total + ((hb_lz4_index_bound(n_out) + 255) & ~(size_t)255); }
+size_t hb_lz4_region_workspace(size_t n_out) { return rg_layout(n_out).total + ((hb_lz4_index_bound(n_out) + 255) & ~(size_t)255); }
 // blocks below 256 KiB stay with the single wavefront (a dozen launches cost more than they save)
-bool hb_lz4_region_wanted(const hb_dec_args &a) { return !a.index && !a.memcpy_payload && a.n >= (256u << 10) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull; }
+// ... and a stream that is longer than any block of a.cap bytes can be is malformed anyway (the workspace has regions for a.cap)
+bool hb_lz4_region_wanted(const hb_dec_args &a) {
+    return !a.index && !a.memcpy_payload && a.n >= (256u << 10) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull && a.n <= a.cap + a.cap / 255 + 16;
+}
 
 __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,15 +53,13 @@ __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t r
 }
 
 // ---- (1a) parse a region from its entry to the first token at / after the next region's start; no copies ----
-__global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
-    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
-    const int lane = threadIdx.x;
+// parses region r from its believed first token (reg[r].entry) to the first token at / after the next region's start; one wavefront.
+// first: nothing is on record yet.  s_win: RG_PWIN + 128 bytes, s_tq: DTQ entries, both this wave's own.
+__device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src, const uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, const uint32_t r,
+                                                const int first, uint8_t *s_win, uint2 *s_tq, const int lane) {
     const uint32_t nreg = plan->nreg;
-    if (!first && plan->pad[1] == 0u) return;                            // no region asked for a full parse
-    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
-        RgRegion *R = reg + r;
-        if (!RFL(R->needfull)) continue;
+    RgRegion *R = reg + r;
+    {
         const uint32_t start = RFL(R->entry);
         const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)RFL(reg[r + 1].b) : n_src;
         uint2 *tr = traces + (size_t)r * RG_TRACE;
@@ -198,6 +199,18 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
             }
             R->needfull = 0;
         }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    const int lane = threadIdx.x;
+    const uint32_t nreg = plan->nreg;
+    if (!first && plan->pad[1] == 0u) return;                            // no region asked for a re-parse
+    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+        if (!RFL(reg[r].needfull)) continue;
+        rg_parse_region(src, n_src, plan, reg, traces, r, first, s_win, s_tq, lane);
         wave_sync();
     }
 }
@@ -209,21 +222,31 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
 // whose belief changed re-parses from the new entry one token at a time until it lands on a position of its recorded trace (the
 // parses have merged: exit unchanged, output length corrected by the difference) or asks for a full parse.  One workgroup, the
 // regions' state in LDS, iterated until nothing moves. ----
-__global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces) {
+// FINISH: the last launch.  What is still moving by then is a long thin chain -- a stretch of the stream whose parses never fall onto the
+// true chain by themselves (periodic data: stray and true chains run side by side), so that every region has to wait for its
+// predecessor's exit and be parsed from there.  Launch pairs would cost more than the hops: this kernel parses the regions that
+// ask for it itself (RG_FPARSERS wavefronts) and goes on, until nothing moves or RG_MAXHOPS.
+template <bool FINISH>
+__global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces) {
     __shared__ uint32_t s_entry[RG_MAXREG], s_exit[RG_MAXREG], s_outl[RG_MAXREG], s_need[RG_MAXREG];
     __shared__ uint32_t s_pm[1024];
-    __shared__ uint32_t s_changed, s_pend;
+    __shared__ uint32_t s_changed, s_pend, s_nlist;
+    __shared__ __attribute__((aligned(16))) uint8_t s_pwin[FINISH ? RG_FPARSERS : 1][FINISH ? RG_PWIN + 128 : 16];
+    __shared__ __attribute__((aligned(16))) uint2 s_ptq[FINISH ? RG_FPARSERS : 1][FINISH ? DTQ : 2];
+    __shared__ uint32_t s_list[FINISH ? RG_FLIST : 1];
     const int t = threadIdx.x;
-    const uint32_t nreg = plan->nreg, bsh = plan->pad[0];
+    const uint32_t nreg = plan->nreg, bsh = plan->pad[0], rs = plan->rs;
     if (plan->pad[2]) return;                                           // an earlier launch came to a standstill with nothing pending
     constexpr uint32_t PER = RG_MAXREG / 1024;
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t r = (uint32_t)t * PER + k;
         if (r < nreg) { s_entry[r] = reg[r].entry; s_exit[r] = reg[r].exit; s_outl[r] = reg[r].outlen; s_need[r] = reg[r].needfull; }
     }
-    if (t == 0) { s_changed = 0; s_pend = 0; }
+    if (t == 0) { s_changed = 0; s_pend = 0; s_nlist = 0; }
     __syncthreads();
     bool capped = true;                                                 // left the loop because of the iteration cap, still moving
+  for (int hop = 0; hop < (FINISH ? RG_MAXHOPS : 1); hop++) {
+    capped = true;
     for (int it = 0; it < 48; it++) {
         uint32_t mx = 0;
         // (a region without a token of its own -- exit == entry -- has nothing to say: if it repeated the position it was handed, a wrong
@@ -241,12 +264,12 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
         for (uint32_t k = 0; k < PER; k++) {
             const uint32_t r = (uint32_t)t * PER + k;
             if (r >= nreg) break;
-            const uint32_t a = run, rb = reg[r].b;
+            const uint32_t a = run, rb = r * rs;                        // (= reg[r].b)
             bool work = r != 0u && a >= rb;                             // (a < b: no predecessor reaches me yet -- unsettled exits in front of me)
             if (work && s_need[r] && s_entry[r] == a) work = false;     // a full parse from this entry is already pending
             if (work && s_entry[r] == a && s_exit[r] != RG_INVALID) work = false;      // belief unchanged
             if (work) {
-                const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)reg[r + 1].b : n_src;
+                const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)(r + 1) * rs : n_src;
                 s_entry[r] = a;
                 s_changed = 1;
                 if ((uint64_t)a >= bnext) { s_exit[r] = a; s_outl[r] = 0; s_need[r] = 0; }     // no token of the chain starts in this region
@@ -294,6 +317,29 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
         __syncthreads();
         if (!go) { capped = false; break; }
     }
+    if constexpr (FINISH) {
+        // the regions that wait for a parse: listed, handed to the parser wavefronts through global memory, results read back
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t r = (uint32_t)t * PER + k;
+            if (r < nreg && s_need[r]) { const uint32_t i = atomicAdd(&s_nlist, 1u); if (i < RG_FLIST) { s_list[i] = r; reg[r].entry = s_entry[r]; reg[r].needfull = 1; } }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t nl = s_nlist < RG_FLIST ? s_nlist : RG_FLIST;
+        if (nl == 0u && !capped) break;                                 // nothing waits, nothing moves: done
+        const uint32_t w = (uint32_t)t >> 6;
+        if (w < RG_FPARSERS)
+            for (uint32_t i = w; i < nl; i += RG_FPARSERS) { rg_parse_region(src, n_src, plan, reg, traces, s_list[i], 0, s_pwin[w], s_ptq[w], t & 63); wave_sync(); }
+        __threadfence_block();
+        __syncthreads();
+        if ((uint32_t)t < nl) {
+            const uint32_t r = s_list[t];
+            s_exit[r] = __builtin_nontemporal_load(&reg[r].exit); s_outl[r] = __builtin_nontemporal_load(&reg[r].outlen); s_need[r] = 0;
+        }
+        if (t == 0) { s_nlist = 0; s_pend = 0; s_changed = 0; }
+        __syncthreads();
+    }
+  }
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t r = (uint32_t)t * PER + k;
         if (r < nreg) { reg[r].entry = s_entry[r]; reg[r].exit = s_exit[r]; reg[r].outlen = s_outl[r]; reg[r].needfull = s_need[r]; }
@@ -549,7 +595,7 @@ __global__ void k_rg_index_head(RgPlan *plan, uint8_t *__restrict__ index, uint6
 // Builds the restart index of an index-less block in the workspace; *index / *index_bytes then go to k_dec_plan / k_dec_indexed as if
 // the frame had carried them (an index that could not be built stays zeroed and is rejected there: serial decode).
 int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size_t *index_bytes, hipStream_t s) {
-    const RgLayout L = rg_layout();
+    const RgLayout L = rg_layout(a.cap);
     uint8_t *w = a.work + 256;                                          // behind the DecPlan
     RgPlan *plan = (RgPlan *)(w + L.plan);
     RgRegion *reg = (RgRegion *)(w + L.reg);
@@ -569,11 +615,11 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
     hb_prof_end(s);
     hb_prof_begin("k_rg_settle", s);
-    for (int k = 0; k < RG_FIXROUNDS; k++) {
-        hipLaunchKernelGGL(k_rg_settle, dim3(1), dim3(1024), 0, s, a.src, (uint64_t)a.n, plan, reg, traces);
-        if (k + 1 < RG_FIXROUNDS)                                       // regions that asked for a re-parse (returns at once when none did)
-            hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
+    for (int k = 0; k < RG_FIXROUNDS; k++) {                           // (both return at once when an earlier round has settled the chain)
+        hipLaunchKernelGGL(k_rg_settle<false>, dim3(1), dim3(1024), 0, s, a.src, (uint64_t)a.n, plan, reg, traces);
+        hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
     }
+    hipLaunchKernelGGL(k_rg_settle<true>, dim3(1), dim3(1024), 0, s, a.src, (uint64_t)a.n, plan, reg, traces);
     hipLaunchKernelGGL(k_rg_scan, dim3(1), dim3(1024), 0, s, plan, reg, (uint64_t)a.n, (uint64_t)a.cap);
     hb_prof_end(s);
     hb_prof_begin("k_rg_index", s);

@@ -782,7 +782,7 @@ __global__ void k_sy_finish(const RgPlan *rg, const SyPlan *sy, DecPlan *dp, int
 // Runs behind k_dec_plan / k_dec_indexed on a block whose index was rebuilt (hb_launch_lz4_region_index): does nothing when that
 // index held; decodes into `dst` otherwise.  `work` = the region workspace, `sym_work` = hb_lz4_sym_workspace(cap) bytes.
 int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_work, int mark_post, hipStream_t s) {
-    const RgLayout RL = rg_layout();
+    const RgLayout RL = rg_layout(a.cap);
     uint8_t *w = a.work + 256;
     RgPlan *rg = (RgPlan *)(w + RL.plan);
     RgRegion *reg = (RgRegion *)(w + RL.reg);

@@ -34,6 +34,9 @@ def _cases(O):
         "f32_24MiB_noshuffle": (f32, 0, 1, None),                     # (barely compressible: may be a memcpy frame)
         "f64_16MiB_shuffle8": (O.synth(O.D_F64, (16 << 20) // 8), 1, 8, True),
         "i32_16MiB_bitshuffle": (O.synth(O.D_I32, (16 << 20) // 4), 2, 4, True),
+        # byte-shuffled integers: three planes of noise (literal runs of tens of MiB) in front of a plane of long runs, whose stream is
+        # PERIODIC -- parses that start off the chain there stay off it (the discovery's slowest case: region after region)
+        "i32_96MiB_shuffle": (O.synth(O.D_I32, (96 << 20) // 4), 1, 4, True),
         "ramp_8MiB": (O.synth(O.D_RAMP, (8 << 20) // 4 + 1), 1, 4, None),            # tiny payload: long matches, few tokens
         "few_valued_12MiB": (rng.integers(0, 4, 12 << 20, dtype=np.uint8) * 64, 0, 1, True),      # token-dense, short offsets
         "period_8192": (np.tile(rng.integers(0, 256, 8192, dtype=np.uint8), 1500), 0, 1, None),   # matches chain period by period
