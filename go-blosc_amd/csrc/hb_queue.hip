@@ -19,6 +19,7 @@ extern "C" {
 size_t hb_frame_bound(size_t n);
 size_t hb_compress_frame_workspace(size_t n);
 size_t hb_decompress_frame_workspace(size_t n_out);
+size_t hb_decompress_frame_workspace_foreign(size_t n_out);
 int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int codec, int level, int shuffle, int typesize,
                           unsigned opts, int device);
 int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, int typesize_override, int device);
@@ -91,7 +92,9 @@ Slot *take_slot(hb_queue *q, int64_t *ticket) {
 
 extern "C" {
 
-hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes) {
+hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes) { return hb_queue_create_ex(device, depth, max_nbytes, 0u); }
+
+hb_queue *hb_queue_create_ex(int device, int depth, size_t max_nbytes, unsigned flags) {
     if (hb_init() != HB_OK || device < 0 || device >= hb_device_count() || depth < 1 || depth > 64 || max_nbytes == 0) return nullptr;
     if (max_nbytes > 0xFFFFFFFFull - HB_HEADER_SIZE - max_nbytes / 255 - 64) return nullptr;
     if (hipSetDevice(device) != hipSuccess) return nullptr;
@@ -104,7 +107,9 @@ hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes) {
                                                             // allocated with 64 bytes of slack: the kernels' 16-byte loads may read past the end
     q->out_bytes = fb;                                      // compress: the frame; decompress: the output (<= max_n)
     q->work_bytes = hb_compress_frame_workspace(max_nbytes);
-    if (hb_decompress_frame_workspace(max_nbytes) > q->work_bytes) q->work_bytes = hb_decompress_frame_workspace(max_nbytes);
+    // (HB_QUEUE_FOREIGN_FRAMES: room for the symbolic decoder, so that frames of other writers decode in parallel too)
+    const size_t dw = (flags & HB_QUEUE_FOREIGN_FRAMES) ? hb_decompress_frame_workspace_foreign(max_nbytes) : hb_decompress_frame_workspace(max_nbytes);
+    if (dw > q->work_bytes) q->work_bytes = dw;
     q->slots.resize((size_t)depth);
     q->kept = hb_ticket_ring(4 * (size_t)depth);
     bool ok = true;
@@ -198,8 +203,8 @@ namespace {
 constexpr int MULTI_DEPTH = 3;
 
 template <class Submit, class OneCall>
-void run_device(int dev, int nd, int nframes, size_t max_n, int64_t *rc, Submit submit, OneCall one_call) {
-    hb_queue *q = max_n ? hb_queue_create(dev, MULTI_DEPTH, max_n) : nullptr;
+void run_device(int dev, int nd, int nframes, size_t max_n, unsigned qflags, int64_t *rc, Submit submit, OneCall one_call) {
+    hb_queue *q = max_n ? hb_queue_create_ex(dev, MULTI_DEPTH, max_n, qflags) : nullptr;
     std::vector<std::pair<int, int64_t>> inflight;        // {frame, ticket}
     auto retire = [&](size_t keep) {
         while (inflight.size() > keep) {
@@ -230,7 +235,7 @@ int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *
             if (hb_device_codec(codec))
                 for (int k = d; k < nframes; k += nd)
                     if (n[k] <= 0xFFFFFFFFull - HB_HEADER_SIZE - n[k] / 255 - 64) max_n = std::max(max_n, n[k]);
-            run_device(d, nd, nframes, max_n, rc,
+            run_device(d, nd, nframes, max_n, 0u, rc,
                        [&](hb_queue *q, int k) -> int64_t {
                            if (!hb_device_codec(codec) || !src[k] || !dst[k] || n[k] == 0) return HB_ERR_BAD_ARG;
                            return hb_queue_compress(q, src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts);
@@ -251,13 +256,17 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
     for (int d = 0; d < nd && d < nframes; d++) {
         th.emplace_back([=]() {
             size_t max_n = 0;                              // largest decoded size among this device's well-formed LZ4 frames
+            unsigned qflags = 0;                           // any large LZ4 frame without a trailer: it may be somebody else's
             for (int k = d; k < nframes; k += nd) {
                 hb_header h;
-                if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (hb_device_codec(h.codec) || (h.flags & HB_FLAG_MEMCPY)))
+                if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (hb_device_codec(h.codec) || (h.flags & HB_FLAG_MEMCPY))) {
                     max_n = std::max(max_n, std::max<size_t>(h.nbytes, 1));
+                    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && h.cbytes >= HB_HEADER_SIZE + (256u << 10) &&
+                        n[k] <= (((size_t)h.cbytes + 7) & ~(size_t)7) + 32) qflags = HB_QUEUE_FOREIGN_FRAMES;
+                }
             }
             if (max_n > 0xFFFFFFFFull - HB_HEADER_SIZE - max_n / 255 - 64) max_n = 0;
-            run_device(d, nd, nframes, max_n, rc,
+            run_device(d, nd, nframes, max_n, qflags, rc,
                        [&](hb_queue *q, int k) -> int64_t {
                            if (!frame[k] || (!dst[k] && cap[k])) return HB_ERR_BAD_ARG;
                            return hb_queue_decompress(q, frame[k], n[k], dst[k], cap[k], typesize_override);

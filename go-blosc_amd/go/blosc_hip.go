@@ -35,7 +35,8 @@ var MinOffloadBytes = 1 << 20
 // Device used by the host-pointer entry points.
 var Device = 0
 
-// ForceDeviceDecode sends frames without a restart index to the device's single-wavefront decoder too.
+// ForceDeviceDecode sends the frames only a single wavefront can decode (no restart index AND a payload below 256 KiB, or a
+// foreign Snappy block) to the device too.
 var ForceDeviceDecode = false
 
 // hasRestartIndex: is there an "HBIX" index after NBytesComp (written by CompressHIP(..., withIndex=true))?
@@ -218,10 +219,14 @@ func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 	if !useHIP || int(h.NBytesOrig) < MinOffloadBytes || (!h.IsMemcpy() && !deviceCodec(Codec(h.VersionLZ))) {
 		return DecompressWithSize(data, typeSize)
 	}
-	// An LZ4 block is one serial chain: without the restart index the device can only put ONE wavefront on it
-	// (~0.15-0.4 GB/s, measured), slower than the pure-Go decoder.  Such frames (anything the CPU path wrote)
-	// stay on the CPU unless the caller insists.
-	if !h.IsMemcpy() && !hasRestartIndex(data, h) && !ForceDeviceDecode {
+	// An LZ4 block is one serial chain.  With the restart index the device decodes it chunk-parallel; without one it
+	// first finds and verifies the token chain itself (payloads from 256 KiB: csrc/hb_lz4_region.hip) and then either
+	// rebuilds the index (frames this library wrote) or decodes symbolically (frames the CPU path wrote, hb_lz4_sym.hip):
+	// 72-85 GB/s device-resident at 1 GiB.  Below that size -- and for Snappy frames of other writers -- only ONE
+	// wavefront can work on it (~0.15-0.4 GB/s, measured), slower than the pure-Go decoder: those stay on the CPU
+	// unless the caller insists.
+	parallel := hasRestartIndex(data, h) || (Codec(h.VersionLZ) != Snappy && int(h.NBytesComp)-HeaderSize >= 256<<10)
+	if !h.IsMemcpy() && !parallel && !ForceDeviceDecode {
 		return DecompressWithSize(data, typeSize)
 	}
 	buf := make([]byte, int(h.NBytesOrig))

@@ -88,7 +88,7 @@ EXPORTS = [
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace", "hb_decompress_frame_workspace_foreign", "hb_lz4_decompress_workspace_foreign",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
-    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_queue_create", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
+    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_queue_create", "hb_queue_create_ex", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
 
 
@@ -144,7 +144,7 @@ def lib():
             "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
             "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),
             "hb_debug_decode_fusion": (None, [i32]), "hb_debug_plane_mask": (None, [u32]),
-            "hb_queue_create": (vp, [i32, i32, sz]), "hb_queue_destroy": (None, [vp]),
+            "hb_queue_create": (vp, [i32, i32, sz]), "hb_queue_create_ex": (vp, [i32, i32, sz, ctypes.c_uint]), "hb_queue_destroy": (None, [vp]),
             "hb_queue_compress": (i64, [vp, vp, sz, vp, sz, i32, i32, i32, i32, u32]),
             "hb_queue_decompress": (i64, [vp, vp, sz, vp, sz, i32]),
             "hb_queue_wait": (i64, [vp, i64]),
@@ -415,8 +415,9 @@ class FrameQueue:
     """`depth` frames in flight on one device.  compress()/decompress() take raw addresses (PinnedBuffer.ptr or any host
     address) and return a ticket; wait(ticket) returns the byte count or raises the reference's sentinel error."""
 
-    def __init__(self, max_nbytes, depth=3, dev=None):
-        self.q = lib().hb_queue_create(device if dev is None else dev, depth, max_nbytes)
+    def __init__(self, max_nbytes, depth=3, dev=None, foreign_frames=False):
+        # foreign_frames: slots get the larger decode workspace, with which frames of other writers decode in parallel too
+        self.q = lib().hb_queue_create_ex(device if dev is None else dev, depth, max_nbytes, 1 if foreign_frames else 0)
         if not self.q:
             raise HipBloscError("hb_queue_create failed")
 

@@ -204,6 +204,10 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
  * A queue belongs to one thread at a time; different queues are independent. */
 typedef struct hb_queue hb_queue;
 hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes);   /* NULL on failure; frames up to max_nbytes uncompressed bytes */
+/* flags: HB_QUEUE_FOREIGN_FRAMES = every slot gets hb_decompress_frame_workspace_foreign(max_nbytes) bytes of workspace (~3x the
+ * frame size more device memory per slot), so that LZ4 frames of other writers -- no restart index, not chunk-local -- decode in parallel */
+#define HB_QUEUE_FOREIGN_FRAMES 1u
+hb_queue *hb_queue_create_ex(int device, int depth, size_t max_nbytes, unsigned flags);
 void hb_queue_destroy(hb_queue *q);                                     /* finishes what is in flight */
 /* enqueue one frame; returns a ticket >= 0 (tickets count up from 0) or an HB_ERR_* code.  When all `depth` slots are
  * in flight the oldest one is finished first (its result is kept for its hb_queue_wait). */

@@ -14,6 +14,11 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INS
 # second SQ pass (8 slots per pass): where waves are parked, LDS behaviour, vector-memory instruction mix
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $O/sq2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-other > $O/sq2.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq3 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-other > $O/sq3.log 2>&1 || true
+# a reference-written frame (oracle encoder) through the token discovery + symbolic decoder: kernel stats of 5 decodes
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/reftrace -- python3 $R/tools/region_debug.py --mib 1024 --dataset f32 --reps 5 > $O/reftrace.log 2>&1 || true
+cp $(ls $O/reftrace/*/*kernel_stats.csv | head -1) $O/reference_frame_kernel_stats.csv || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/owntrace -- python3 $R/tools/region_debug.py --mib 1024 --dataset f32 --reps 5 --writer device > $O/owntrace.log 2>&1 || true
+cp $(ls $O/owntrace/*/*kernel_stats.csv | head -1) $O/indexless_frame_kernel_stats.csv || true
 cd $R
 # config 2 (filters only): kernel stats + HBM traffic of the shuffle / unshuffle kernels
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ftrace -- python3 $R/bench.py --mode filter --steps 5 --warmup 2 --no-cpu > $O/ftrace.log 2>&1

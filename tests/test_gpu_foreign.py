@@ -235,3 +235,29 @@ def test_index_less_frames_at_full_size(hb, O):
     assert L.hb_last_result_flags() & 1, "the reference-shaped frame was not decoded in parallel"
     assert np.array_equal(back[:m], x[:m]), "reference-shaped frame: device decode differs"
     print(f"reference-shaped 256 MiB frame host->host: {m / dt / 1e9:.2f} GB/s")
+
+
+def test_queue_with_room_for_foreign_frames(hb, O):
+    # hb_queue_create_ex(HB_QUEUE_FOREIGN_FRAMES): reference-shaped frames through the pipelined queue decode in parallel
+    x = O.synth(O.D_F32, (8 << 20) // 4)
+    f = O.compress_frame(x, shuffle=1, typesize=4)
+    n = x.nbytes
+    for foreign, want in ((False, 0), (True, 1)):
+        q = hb.FrameQueue(n, depth=2, foreign_frames=foreign)
+        src, dst = hb.PinnedBuffer(f.size), hb.PinnedBuffer(n)
+        ctypes.memmove(src.ptr, f.ctypes.data, f.size)
+        tickets = [q.decompress(src.ptr, f.size, dst.ptr, n) for _ in range(3)]
+        for t in tickets:
+            assert q.wait(t) == n
+        assert np.array_equal(np.frombuffer(dst.view, np.uint8), x)
+        q.close(); src.close(); dst.close()
+    # the batch entry point looks at its frames and picks the larger workspace itself
+    L = hb.lib()
+    outs = [np.zeros(n, np.uint8) for _ in range(2)]
+    frames = (ctypes.c_void_p * 2)(f.ctypes.data, f.ctypes.data)
+    sizes = (ctypes.c_size_t * 2)(f.size, f.size)
+    dsts = (ctypes.c_void_p * 2)(outs[0].ctypes.data, outs[1].ctypes.data)
+    caps = (ctypes.c_size_t * 2)(n, n)
+    rcs = (ctypes.c_int64 * 2)()
+    assert L.hb_decompress_frames_multi(2, frames, sizes, dsts, caps, rcs, 0) == 0
+    assert list(rcs) == [n, n] and all(np.array_equal(o, x) for o in outs)
