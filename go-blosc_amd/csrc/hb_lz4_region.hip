@@ -60,7 +60,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
     const uint32_t nreg = plan->nreg;
     RgRegion *R = reg + r;
     {
-        const uint32_t start = RFL(R->entry);
+        uint32_t start = RFL(R->entry);
         const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)RFL(reg[r + 1].b) : n_src;
         uint2 *tr = traces + (size_t)r * RG_TRACE;
         const uint32_t rb = RFL(R->b), bsh = plan->pad[0];                 // bucket = (position - b) >> bsh
@@ -91,6 +91,60 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             wave_sync();
         };
         wave_sync();
+        if (first && r != 0u) {
+            // A better first guess than "a token starts at my first byte".  Where literal runs are long, tokens are rare and a parse that
+            // starts inside literal bytes may not meet one for the whole region (measured on this library's own streams: the exits
+            // of 36 % of the regions wrong after the first pass, in chains of up to 15 regions); where the stream is periodic (a
+            // plane of long runs) a stray parse never falls onto the true chain at all.  Both kinds of stream are full of LONG
+            // LENGTH EXTENSIONS, and those are easy to spot and say where a token is: a run of >= 15 bytes FF (found 1 KiB per step
+            // as an aligned all-FF quadword) is the extension of a literal length when the byte in front of it is F? -- that byte
+            // is the token -- and of a match length otherwise -- the next token starts behind the byte that ends the run.  The first
+            // such run in the region decides where the parse starts.  Only a guess, like the other one: the chain is verified as a
+            // whole, and a pattern in the data itself costs what a stray start costs anyway.
+            uint32_t found = RG_INVALID;                                  // token position, relative to `start`
+            int tries = 4;
+            for (uint64_t at = start; at < bnext && found == RG_INVALID && tries > 0; at += RG_PWIN - 512u) {
+                refill(at);
+                const uint32_t endo = wsh + wlen;                          // LDS offsets [wsh, endo) hold the window
+                uint32_t from = wsh;                                       // runs that end in front of this offset were looked at
+                for (uint32_t g0 = 0; 16u * g0 < endo && found == RG_INVALID && tries > 0; g0 += 64) {
+                    const uint32_t g = g0 + (uint32_t)lane;
+                    u32x4 v; v.x = 0; v.y = 0; v.z = 0; v.w = 0;
+                    if (16u * g + 16u <= endo) v = ((const u32x4 *)s_win)[g];
+                    const bool h0 = (v.x & v.y) == 0xFFFFFFFFu && 16u * g >= from, h1 = (v.z & v.w) == 0xFFFFFFFFu && 16u * g + 8u >= from;
+                    const unsigned long long m = hb_ballot(h0 || h1);
+                    if (!m) continue;
+                    const int j = __builtin_ctzll(m);
+                    const uint32_t q = 16u * (g0 + (uint32_t)j) + (__builtin_amdgcn_readlane((uint32_t)h0, j) ? 0u : 8u);   // an all-FF quadword
+                    // where the run starts ...
+                    uint32_t rs0 = q;
+                    bool open = true;
+                    while (open && rs0 > wsh) {
+                        const uint32_t idx = rs0 - 1u - (uint32_t)lane;
+                        const uint32_t byte = (rs0 >= 1u + (uint32_t)lane && idx >= wsh) ? (uint32_t)s_win[idx] : 0u;
+                        const unsigned long long nm = hb_ballot(byte != 255u);
+                        if (nm) { rs0 -= (uint32_t)__builtin_ctzll(nm); open = false; } else rs0 -= 64u;
+                    }
+                    // ... and where it ends (the first byte that is not FF belongs to the extension)
+                    uint32_t re = q + 8u;
+                    bool eopen = true;
+                    while (eopen && re < endo) {
+                        const uint32_t idx = re + (uint32_t)lane;
+                        const uint32_t byte = idx < endo ? (uint32_t)s_win[idx] : 255u;
+                        const unsigned long long nm = hb_ballot(byte != 255u);
+                        if (nm) { re += (uint32_t)__builtin_ctzll(nm); eopen = false; } else re += 64u;
+                    }
+                    tries--;
+                    if (!open && rs0 > wsh && ((uint32_t)s_win[rs0 - 1u] >> 4) == 15u) found = (uint32_t)(at - start) + (rs0 - 1u - wsh);
+                    else if (!open && !eopen && re + 1u < endo) found = (uint32_t)(at - start) + (re + 1u - wsh);
+                    from = eopen ? endo : re + 1u;                        // (a run that leaves the window on either side is skipped)
+                    if (found == RG_INVALID) g0 = (from >> 4) / 64u * 64u - 64u;     // go on behind it (the loop adds 64)
+                }
+            }
+            // (parsing from the first byte as well and keeping that parse when it comes by the spotted token was measured: the dense
+            // regions that miss it pay twice, +2 ms per GiB; starting at the token costs the fix round 0.4 ms instead)
+            if (found != RG_INVALID && (uint64_t)start + found < bnext) { start += found; si = start; }
+        }
         for (;;) {
             if (si >= bnext) { exitp = (uint32_t)si; break; }           // (si <= n_src always; bnext <= n_src)
             if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
@@ -196,6 +250,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 R->exit = ex; R->outlen = (uint32_t)out;
                 R->entry0 = start; R->exit0 = ex; R->outlen0 = (uint32_t)out; R->ntrace = ntok < RG_DENSE ? ntok : RG_DENSE;
                 R->pad0 = start;                                         // the whole record lies on this parse
+                if (first) R->entry = start;                             // (the guess may have moved to a spotted token)
             }
             R->needfull = 0;
         }
@@ -483,95 +538,36 @@ __global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src
     for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
         const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit);
         if (RFL(reg[r].outlen) == 0u || start >= exitp) continue;
-        uint64_t si = start, wpos = 0, out = reg[r].opos;
-        uint32_t wlen = 0, wsh = 0, nq = 0;
-        bool bad = false;
-        auto refill = [&](uint64_t at) __attribute__((always_inline)) {
-            const uint8_t *g = src + at;
-            wsh = (uint32_t)((uintptr_t)g & 15u);
-            const uint64_t left = n_src - at;
-            wlen = (uint32_t)(left < (uint64_t)(RG_PWIN - 16u) ? left : (uint64_t)(RG_PWIN - 16u));
-            const u32x4 *ga = (const u32x4 *)(g - wsh);
-            const uint32_t nv = (wsh + wlen + 15u) >> 4;
-            wave_sync();
-            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
-            wpos = at;
-            wave_sync();
+        uint64_t out = reg[r].opos;
+        // unit boundaries of a sequence: at its token, inside its literal run (any number of them), never in its match
+        auto batch = [&](uint32_t cnt, uint32_t tp, uint32_t ls, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t lp) __attribute__((always_inline)) -> bool {
+            (void)off; (void)lp;
+            const uint32_t olen = (uint32_t)lane < cnt ? lit + mlen : 0u;
+            const uint32_t incl = wave_incl_scan_dpp(olen);
+            const uint64_t d0 = out + incl - olen;                       // where my sequence's output starts
+            uint64_t U = (d0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);                // first unit boundary at / after it
+            bool inm = false;
+            if ((uint32_t)lane < cnt) {
+                if (U == d0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
+                for (; U < d0 + lit && U < N; U += HB_CHUNK) rg_emit(ents, U, ls + (uint32_t)(U - d0), (uint32_t)(d0 + lit - U), tp);
+                if (U < d0 + lit + mlen && U < N) inm = true;           // a unit boundary at the start of / inside a match
+            }
+            if (hb_ballot(inm)) return false;
+            out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+            return true;
         };
-        wave_sync();
-        while (!bad && si < exitp) {
-            if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
-            uint32_t rel = (uint32_t)(si - wpos);
-            const uint64_t tolim = (uint64_t)exitp - wpos;
-            const uint32_t lim = (uint32_t)(tolim < (uint64_t)wlen ? tolim : (uint64_t)wlen);
-            const bool stop = rg_fill(s_win, wsh, lim, rel, nq, s_tq, lane);
-            while (nq > 0u) {
-                const uint32_t cntb = nq < 64u ? nq : 64u;
-                const uint2 e = s_tq[lane];
-                const uint32_t lit = e.y & 0xFFFFu, mlen = e.y >> 16;
-                const uint32_t tp = (uint32_t)(wpos + (e.x & 0xFFFFu)), ls = tp + 1u + (e.x >> 16);
-                const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
-                const uint32_t incl = wave_incl_scan_dpp(olen);
-                const uint64_t d0 = out + incl - olen;                   // where my sequence's output starts
-                uint64_t U = (d0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);            // first unit boundary at / after it
-                bool inm = false;
-                if ((uint32_t)lane < cntb) {
-                    if (U == d0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
-                    for (; U < d0 + lit && U < N; U += HB_CHUNK) rg_emit(ents, U, ls + (uint32_t)(U - d0), (uint32_t)(d0 + lit - U), tp);
-                    if (U < d0 + lit + mlen && U < N) inm = true;       // a unit boundary at the start of / inside a match
-                }
-                if (hb_ballot(inm)) { bad = true; nq = 0; break; }
-                out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-                const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
-                nq -= cntb;
-                if ((uint32_t)lane < nq) s_tq[lane] = rest;
-            }
-            if (bad) break;
-            const bool moved = (wpos + rel) != si;
-            si = wpos + rel;
-            if (moved && !stop) continue;
-            if (si >= exitp) break;
-            if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src && wpos + wlen < exitp) continue;
-            // ---- one token the slow way: runs of any length ----
-            if (si < wpos || si >= wpos + wlen) refill(si);
-            rel = (uint32_t)(si - wpos);
-            const uint32_t tp = (uint32_t)si;
-            const uint32_t tok = RFL((uint32_t)s_win[wsh + rel]);
-            rel++;
-            uint32_t ll = tok >> 4;
-            {
-                const uint64_t span = n_src - wpos;
-                if (ll == 15u && !dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { bad = true; break; }
-            }
-            uint64_t p = wpos + rel;
-            const uint32_t ls = (uint32_t)p;
-            if ((uint64_t)ll > n_src - p) { bad = true; break; }
-            p += ll;
-            uint32_t ml = 0;
-            if (p != n_src) {
-                if (n_src - p < 2) { bad = true; break; }
-                p += 2;
-                ml = (tok & 15u) + 4u;
-                if ((tok & 15u) == 15u) {
-                    if (p < wpos || p - wpos + 64u > wlen) refill(p);
-                    uint32_t rel2 = (uint32_t)(p - wpos);
-                    const uint64_t span = n_src - wpos;
-                    if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel2, ml, lane)) { bad = true; break; }
-                    p = wpos + rel2;
-                }
-            }
-            {   // unit boundaries of this sequence: token start, inside the literal run (any number of them), never in the match
-                const uint64_t d0 = out, U0 = (d0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
-                if (U0 == d0 && U0 < N && lane == 0) rg_emit(ents, U0, tp, HB_IDX_AT_TOKEN, 0u);
-                for (uint64_t U = (U0 == d0 ? U0 + HB_CHUNK : U0) + (uint64_t)lane * HB_CHUNK; U < d0 + ll && U < N; U += 64ull * HB_CHUNK)
-                    rg_emit(ents, U, ls + (uint32_t)(U - d0), (uint32_t)(d0 + ll - U), tp);
-                const uint64_t m0 = d0 + ll, Um = (m0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
-                if (ml && Um < m0 + ml && Um < N) bad = true;            // a boundary at the start of / inside the match
-            }
-            out += (uint64_t)ll + ml;
-            si = p;
-        }
-        if (bad && lane == 0) atomicExch(&plan->fail, 1u);
+        auto single = [&](uint32_t tp, uint32_t ls, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t tok) __attribute__((always_inline)) -> bool {
+            (void)off; (void)tok;
+            const uint64_t d0 = out, U0 = (d0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+            if (U0 == d0 && U0 < N && lane == 0) rg_emit(ents, U0, tp, HB_IDX_AT_TOKEN, 0u);
+            for (uint64_t U = (U0 == d0 ? U0 + HB_CHUNK : U0) + (uint64_t)lane * HB_CHUNK; U < d0 + lit && U < N; U += 64ull * HB_CHUNK)
+                rg_emit(ents, U, ls + (uint32_t)(U - d0), (uint32_t)(d0 + lit - U), tp);
+            const uint64_t m0 = d0 + lit, Um = (m0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+            if (mlen && Um < m0 + mlen && Um < N) return false;         // a boundary at the start of / inside the match
+            out += (uint64_t)lit + mlen;
+            return true;
+        };
+        if (!rg_walk(src, n_src, start, exitp, s_win, s_tq, lane, batch, single) && lane == 0) atomicExch(&plan->fail, 1u);
         wave_sync();
     }
 }
