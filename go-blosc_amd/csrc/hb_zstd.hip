@@ -229,24 +229,37 @@ int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *ds
         at += c; out += (size_t)d;
     }
     size_t got = 0;
+    // with an un-filter to run, every slice goes up to the device the moment its zstd frame is decoded: the uploads of the first
+    // slices overlap the decoding of the later ones (one stream; the pinned staging buffer is the source)
+    hipStream_t up = nullptr;
+    bool uploaded = false;
+    if (!rc && table_ok && unf >= 0 && n) {
+        d_a = (uint8_t *)cache_get(false, device, n, &b_a);
+        d_b = (uint8_t *)cache_get(false, device, n, &b_b);
+        if (!d_a || !d_b || hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) rc = HB_ERR_HIP;
+    }
     if (!rc && table_ok) {
         std::atomic<size_t> next{0};
         std::atomic<int> failed{0};
         auto worker = [&]() {
+            if (up && hipSetDevice(device) != hipSuccess) { failed = HB_ERR_HIP; return; }
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= tasks.size() || failed.load()) return;
                 const Task &t = tasks[i];
                 const size_t r = z->decompress(target + t.dst, t.dlen, p + t.src, t.clen);
                 if (z->is_error(r) || r != t.dlen) { failed = HB_ERR_DECOMPRESSION_FAILED; return; }   // blosc.go:411-413
+                if (up && t.dlen && hipMemcpyAsync(d_a + t.dst, target + t.dst, t.dlen, hipMemcpyHostToDevice, up) != hipSuccess) { failed = HB_ERR_HIP; return; }
             }
         };
         std::vector<std::thread> th;
         const int nt = (int)std::min<size_t>((size_t)host_threads(), tasks.size());
         for (int t = 0; t < nt; t++) th.emplace_back(worker);
         for (auto &t : th) t.join();
+        if (up && hipStreamSynchronize(up) != hipSuccess && !failed.load()) failed = HB_ERR_HIP;
         if (failed.load()) rc = failed.load();
         got = out;
+        uploaded = up != nullptr && !rc;
     } else if (!rc) {                                                 // no usable frame table: one call, as DecodeAll
         const size_t r = z->decompress(target, n, p, plen);
         if (z->is_error(r))                                           // 70 = ZSTD_error_dstSize_tooSmall: decodes, but to more than NBytesOrig
@@ -255,13 +268,14 @@ int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *ds
     }
     if (!rc && got != n) rc = HB_ERR_SIZE_MISMATCH;                   // blosc.go:429-431
     if (!rc && unf >= 0 && n) {
-        d_a = (uint8_t *)cache_get(false, device, n, &b_a);
-        d_b = (uint8_t *)cache_get(false, device, n, &b_b);
+        if (!d_a) d_a = (uint8_t *)cache_get(false, device, n, &b_a);
+        if (!d_b) d_b = (uint8_t *)cache_get(false, device, n, &b_b);
         if (!d_a || !d_b) rc = HB_ERR_HIP;
-        if (!rc && hipMemcpy(d_a, h_f, n, hipMemcpyHostToDevice) != hipSuccess) rc = HB_ERR_HIP;
+        if (!rc && !uploaded && hipMemcpy(d_a, h_f, n, hipMemcpyHostToDevice) != hipSuccess) rc = HB_ERR_HIP;
         if (!rc) rc = hb_launch_filter(unf, d_b, d_a, n, ts, nullptr);
         if (!rc && hipMemcpy(dst, d_b, n, hipMemcpyDeviceToHost) != hipSuccess) rc = HB_ERR_HIP;
     }
+    if (up) (void)hipStreamDestroy(up);
     cache_put(false, device, d_a, b_a);                               // the copies above were synchronous
     cache_put(false, device, d_b, b_b);
     cache_put(true, device, h_f, b_h);
