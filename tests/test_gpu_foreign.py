@@ -261,3 +261,21 @@ def test_queue_with_room_for_foreign_frames(hb, O):
     rcs = (ctypes.c_int64 * 2)()
     assert L.hb_decompress_frames_multi(2, frames, sizes, dsts, caps, rcs, 0) == 0
     assert list(rcs) == [n, n] and all(np.array_equal(o, x) for o in outs)
+
+
+def test_random_valid_blocks_decode_exactly(hb, O):
+    # blocks no encoder wrote: sequences drawn at random by tests/tools/lz4_stream_gen.py (offsets to 65535, every small period, runs and
+    # literal runs of hundreds of KiB, sequences without literals ...); expected bytes: the oracle decoder's
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import lz4_stream_gen as G
+    for seed, flags, ts in ((11, 0, 1), (12, 1, 4), (13, 4, 4), (14, 0, 1), (15, 1, 8)):
+        rng = np.random.default_rng(seed)
+        block, n = G.random_block(rng, (10 << 20) + seed * 4099, align=32 if flags == 4 else ts)
+        frame = struct.pack("<BBBBIII", 2, hb.LZ4, flags, ts, n, n, 16 + len(block)) + block
+        want = O.decompress_frame(np.frombuffer(frame, np.uint8)).tobytes()
+        assert len(want) == n
+        assert hb.Decompress(frame) == want, seed
+        assert hb.lib().hb_last_result_flags() & 1, seed
+        if not flags:
+            assert hb.codecs[hb.LZ4].Decompress(block, n) == want, seed
