@@ -559,4 +559,27 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     return (int64_t)r.bytes;
 }
 
+int64_t hb_cblosc_decompress(const void *frame, size_t n, void *dst, size_t cap, int device) {
+    hb_cblosc_header h;
+    int rc = hb_cblosc_parse_header(frame, n, &h);
+    if (rc) return rc;
+    if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
+    if ((!dst && h.nbytes)) return HB_ERR_BAD_ARG;
+    if (!(h.flags & 0x02u) && h.codec_format != 1) return HB_ERR_INVALID_CODEC;
+    rc = select_device(device);
+    if (rc) return rc;
+    Scratch sc(device);
+    const size_t wb = hb_cblosc_decompress_workspace(h.nbytes, h.blocksize, h.typesize);
+    uint8_t *d_frame = sc.get(n + 64), *d_dst = sc.get((size_t)h.nbytes + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_frame || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
+    HB_HIP_TRY(hipMemcpy(d_frame, frame, h.cbytes, hipMemcpyHostToDevice));
+    rc = hb_cblosc_decompress_dev(&h, d_frame, n, d_dst, h.nbytes, d_work, wb, (hb_result *)d_res, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;
+    if (r.bytes) HB_HIP_TRY(hipMemcpy(dst, d_dst, r.bytes, hipMemcpyDeviceToHost));
+    return (int64_t)r.bytes;
+}
+
 }  // extern "C"

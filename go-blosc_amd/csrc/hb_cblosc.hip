@@ -1,0 +1,208 @@
+// hb_cblosc.hip — SURVEY §8 row f4: frames in the C-Blosc-1 wire format (what go-blosc's README.md:20 claims to read and write and
+// blosc.go does not: SURVEY §0.2), decoded on the device.  The format as c-blosc 1.21 writes it (blosc.c blosc_d / blosc_c; checked
+// against /opt/conda/lib/libblosc.so.1.21.0, which is also what the tests produce their frames with):
+//
+//   header  16 bytes { version = 2, versionlz, flags, typesize, nbytes u32, blocksize u32, cbytes u32 }
+//           flags: 0x01 byte shuffle, 0x02 memcpyed, 0x04 bit shuffle, 0x10 blocks are not split, bits 5-7 codec format
+//           (0 blosclz, 1 lz4 / lz4hc, 2 snappy, 3 zlib, 4 zstd)
+//   memcpyed: nbytes raw bytes follow.  Else bstarts: int32[nblocks], the offset of every block from the start of the frame;
+//   a block is `typesize` streams (or ONE: flag 0x10, and always the last block when it is shorter than blocksize), a stream
+//   is { int32 cbytes, data }: an LZ4 block that decodes to blocksize / nstreams bytes -- or those bytes themselves when
+//   cbytes says exactly that size.  The filter works per BLOCK: byte shuffle = the block's elements transposed to `typesize`
+//   byte planes (the streams ARE the planes; the bytes behind the last whole element stay where they are); bit shuffle =
+//   element bit (byte j, bit k) of all elements of the block gathered in row 8 j + k, eight elements per byte, lowest first --
+//   only when the block holds a multiple of 8 elements, else the block is stored unfiltered (shuffle.c blosc_internal_bitshuffle).
+//
+// Blocks and streams are independent, so there is no discovery problem here: k_cb_plan lists the streams (one lane per block
+// walks its cbytes fields), k_cb_decode puts one wavefront on every stream (the serial block decoder of hb_dec_common.h: streams
+// are 8-256 KiB, hundreds to thousands per frame), k_cb_unfilter undoes the per-block filter.  LZ4 / LZ4HC and memcpyed frames
+// only: the other codec formats are entropy coders or blosclz.
+#include "hb_sym_decode.h"
+
+#define CB_FLAG_SHUFFLE    0x01u
+#define CB_FLAG_MEMCPY     0x02u
+#define CB_FLAG_BITSHUFFLE 0x04u
+#define CB_FLAG_DONTSPLIT  0x10u
+
+struct CbStream { uint32_t src, csize, dst, usize; };
+struct CbPlan { uint32_t fail, nblocks, nsplit, pad; };
+
+static inline size_t cb_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// ---- the streams of every block ----
+__global__ void k_cb_plan(const uint8_t *__restrict__ frame, uint64_t n, uint32_t nbytes, uint32_t blocksize, uint32_t cbytes, uint32_t typesize, uint32_t flags,
+                          CbPlan *plan, CbStream *streams) {
+    const uint32_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t leftover = nbytes % blocksize;
+    const bool lastshort = b + 1 == nblocks && leftover != 0u;
+    const uint32_t bsize = lastshort ? leftover : blocksize;
+    const uint32_t nsplit_frame = (flags & CB_FLAG_DONTSPLIT) ? 1u : typesize;
+    const uint32_t nsplit = lastshort ? 1u : nsplit_frame;
+    const uint32_t neblock = bsize / nsplit;
+    CbStream *out = streams + (size_t)b * nsplit_frame;
+    for (uint32_t s = 0; s < nsplit_frame; s++) { CbStream z; z.src = 0; z.csize = 0; z.dst = 0; z.usize = 0; out[s] = z; }
+    uint32_t p = (uint32_t)frame[16 + 4 * b] | ((uint32_t)frame[17 + 4 * b] << 8) | ((uint32_t)frame[18 + 4 * b] << 16) | ((uint32_t)frame[19 + 4 * b] << 24);
+    bool bad = neblock == 0u || (uint64_t)neblock * nsplit != bsize;                  // (blosc_c only splits what divides)
+    for (uint32_t s = 0; s < nsplit && !bad; s++) {
+        if ((uint64_t)p + 4u > cbytes) { bad = true; break; }
+        const uint32_t cb = (uint32_t)frame[p] | ((uint32_t)frame[p + 1] << 8) | ((uint32_t)frame[p + 2] << 16) | ((uint32_t)frame[p + 3] << 24);
+        p += 4u;
+        if (cb == 0u || cb > 0x7FFFFFFFu || (uint64_t)p + cb > cbytes || cb > neblock + neblock / 255u + 16u) { bad = true; break; }
+        CbStream st; st.src = p; st.csize = cb; st.dst = b * blocksize + s * neblock; st.usize = neblock;
+        out[s] = st;
+        p += cb;
+    }
+    if (bad) atomicExch(&plan->fail, 1u);
+}
+
+// ---- one wavefront per stream ----
+// The decoder is pass A of the symbolic decoder without the symbols (hb_sym_decode.h): 13 KiB of LDS per wavefront -- an image of the last
+// 4 KiB of output, older sources read back from HBM -- so that a dozen streams per CU are in flight.  (First version: the serial
+// block decoder with its 64 KiB history in LDS, one wavefront per CU: 21 GB/s on 256 MiB of float32.)
+__global__ __launch_bounds__(64) void k_cb_decode(const uint8_t *__restrict__ frame, CbPlan *plan, const CbStream *__restrict__ streams, uint32_t nstreams,
+                                                   uint8_t *dst) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    __shared__ __attribute__((aligned(16))) uint8_t s_d[SY_IMG + 64];
+    const int lane = threadIdx.x;
+    if (plan->fail) return;
+    for (uint32_t i = blockIdx.x; i < nstreams; i += gridDim.x) {
+        const CbStream st = streams[i];
+        if (st.usize == 0u) continue;
+        if (st.csize == st.usize) { wave_copy_g2g(dst + st.dst, frame + st.src, st.usize, lane); continue; }      // stored
+        uint32_t out = st.dst;
+        bool parked;
+        const bool ok = sy_decode_unit<false>(frame + st.src, (uint64_t)st.csize, 0u, st.csize, st.dst, st.dst, out, dst, nullptr, s_win, s_tq, s_d, nullptr,
+                                              lane, 1, 0u, 0u, nullptr, nullptr, nullptr, parked, st.dst + st.usize);
+        if ((!ok || out != st.dst + st.usize) && lane == 0) atomicExch(&plan->fail, 1u);     // blosc_d: "nbytes != neblock -> -2"
+        wave_sync();
+    }
+}
+
+// ---- the per-block filters, undone ----
+// byte shuffle: block bytes [plane 0 | plane 1 | ...] -> elements; one thread per element (typesize 4 / 8: one store)
+__global__ void k_cb_unshuffle(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t nbytes, uint32_t blocksize, uint32_t ts) {
+    const uint32_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const uint32_t per = blocksize / ts + 1u;                                          // threads per block: elements + one for the tail
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)nblocks * per; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i / per), e = (uint32_t)(i % per);
+        const uint32_t base = b * blocksize, bsize = nbytes - base < blocksize ? nbytes - base : blocksize, nel = bsize / ts;
+        if (e < nel) {
+            const uint8_t *s = src + base + e;
+            uint8_t *d = dst + base + (size_t)e * ts;
+            if (ts == 4u) { st4u(d, (uint32_t)s[0] | ((uint32_t)s[nel] << 8) | ((uint32_t)s[2u * nel] << 16) | ((uint32_t)s[3u * nel] << 24)); }
+            else for (uint32_t j = 0; j < ts; j++) d[j] = s[(size_t)j * nel];
+        } else if (e == nel) {
+            for (uint32_t k = nel * ts; k < bsize; k++) dst[base + k] = src[base + k];   // the bytes behind the last whole element
+        }
+    }
+}
+// bit shuffle: one thread per group of 8 elements
+__global__ void k_cb_bitunshuffle(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t nbytes, uint32_t blocksize, uint32_t ts) {
+    const uint32_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const uint32_t per = blocksize / (8u * ts) + 1u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)nblocks * per; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i / per), g = (uint32_t)(i % per);
+        const uint32_t base = b * blocksize, bsize = nbytes - base < blocksize ? nbytes - base : blocksize, nel = bsize / ts;
+        if (nel % 8u != 0u) {                                                           // not filtered at all: the threads of the block copy it
+            for (uint32_t k = g; k < bsize; k += per) dst[base + k] = src[base + k];
+            continue;
+        }
+        const uint32_t ng = nel / 8u;                                                   // bytes per bit row
+        if (g < ng) {
+            for (uint32_t j = 0; j < ts; j++) {
+                uint64_t x = 0;                                                         // byte k = row 8 j + k, elements 8 g .. 8 g + 7
+                for (uint32_t k = 0; k < 8u; k++) x |= (uint64_t)src[base + (size_t)(8u * j + k) * ng + g] << (8u * k);
+                // 8 x 8 bit transpose: out byte i, bit k = in byte k, bit i
+                uint64_t t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x ^= t ^ (t << 7);
+                t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
+                t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
+                for (uint32_t e = 0; e < 8u; e++) dst[base + (size_t)(8u * g + e) * ts + j] = (uint8_t)(x >> (8u * e));
+            }
+        } else if (g == ng) {
+            for (uint32_t k = nel * ts; k < bsize; k++) dst[base + k] = src[base + k];
+        }
+    }
+}
+
+__global__ void k_cb_result(const CbPlan *plan, hb_result *result, uint64_t nbytes) {
+    result->flags = 1; result->total_bytes = nbytes; result->reserved = 0;
+    if (plan->fail) { result->status = HB_ERR_DECOMPRESSION_FAILED; result->bytes = 0; }
+    else { result->status = HB_OK; result->bytes = nbytes; }
+}
+__global__ void k_cb_init(CbPlan *plan) { plan->fail = 0; }
+
+extern "C" {
+
+// header fields of a C-Blosc-1 frame (host side); HB_OK or the error a malformed header gets
+int hb_cblosc_parse_header(const void *frame, size_t n, hb_cblosc_header *out) {
+    if (!frame || !out) return HB_ERR_BAD_ARG;
+    if (n < 16) return HB_ERR_INVALID_HEADER;
+    const uint8_t *f = (const uint8_t *)frame;
+    auto rd = [&](int at) { return (uint32_t)f[at] | ((uint32_t)f[at + 1] << 8) | ((uint32_t)f[at + 2] << 16) | ((uint32_t)f[at + 3] << 24); };
+    out->version = f[0]; out->versionlz = f[1]; out->flags = f[2]; out->typesize = f[3];
+    out->nbytes = rd(4); out->blocksize = rd(8); out->cbytes = rd(12);
+    out->codec_format = f[2] >> 5;
+    if (out->version != 2) return HB_ERR_INVALID_VERSION;                              // BLOSC_VERSION_FORMAT
+    if (out->typesize == 0) return HB_ERR_INVALID_HEADER;
+    if (out->cbytes < 16 || out->cbytes > n) return HB_ERR_INVALID_DATA;
+    if (out->nbytes && out->blocksize == 0) return HB_ERR_INVALID_HEADER;
+    return HB_OK;
+}
+
+size_t hb_cblosc_decompress_workspace(size_t nbytes, size_t blocksize, size_t typesize) {
+    const size_t nblocks = blocksize ? (nbytes + blocksize - 1) / blocksize : 0;
+    return 256 + cb_align(nblocks * (typesize ? typesize : 1) * sizeof(CbStream)) + cb_align(nbytes + 64);
+}
+
+// d_frame: the frame in device memory (n bytes available), d_dst: hdr.nbytes bytes.  Asynchronous on `stream`; *d_result says how it went.
+int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, size_t n, void *d_dst, size_t cap, void *d_work, size_t work_bytes,
+                             hb_result *d_result, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (!hdr || !d_frame || (!d_dst && cap) || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nbytes = hdr->nbytes, blocksize = hdr->blocksize, ts = hdr->typesize, flags = hdr->flags;
+    if (hdr->cbytes > n || hdr->cbytes < 16) return HB_ERR_INVALID_DATA;
+    if (nbytes > cap) return HB_ERR_SHORT_BUFFER;
+    if (work_bytes < hb_cblosc_decompress_workspace(nbytes, blocksize, ts)) return HB_ERR_SHORT_BUFFER;
+    uint8_t *w = (uint8_t *)d_work;
+    CbPlan *plan = (CbPlan *)w;
+    hipLaunchKernelGGL(k_cb_init, dim3(1), dim3(1), 0, s, plan);
+    if (nbytes == 0) { hipLaunchKernelGGL(k_cb_result, dim3(1), dim3(1), 0, s, plan, d_result, (uint64_t)0); return HB_OK; }
+    if (flags & CB_FLAG_MEMCPY) {                                       // blosc.c: "memcpyed": the raw bytes follow the header
+        if ((uint64_t)hdr->cbytes < 16ull + nbytes) return HB_ERR_INVALID_DATA;
+        HB_HIP_TRY(hipMemcpyAsync(d_dst, (const uint8_t *)d_frame + 16, nbytes, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_cb_result, dim3(1), dim3(1), 0, s, plan, d_result, (uint64_t)nbytes);
+        return HB_OK;
+    }
+    if (hdr->codec_format != 1) return HB_ERR_INVALID_CODEC;            // lz4 / lz4hc only
+    const uint32_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    if (16ull + 4ull * nblocks > hdr->cbytes) return HB_ERR_INVALID_DATA;
+    const uint32_t nsplit = (flags & CB_FLAG_DONTSPLIT) ? 1u : ts;
+    CbStream *streams = (CbStream *)(w + 256);
+    uint8_t *staged = w + 256 + cb_align((size_t)nblocks * nsplit * sizeof(CbStream));
+    // blosc_d: the byte shuffle counts for typesize > 1 only (and comes first), the bit shuffle for any typesize
+    const bool unshuf = (flags & CB_FLAG_SHUFFLE) && ts > 1, unbit = !unshuf && (flags & CB_FLAG_BITSHUFFLE);
+    const bool filtered = unshuf || unbit;
+    uint8_t *target = filtered ? staged : (uint8_t *)d_dst;
+    const uint32_t nstreams = nblocks * nsplit;
+    hb_prof_begin("k_cb_decode", s);
+    hipLaunchKernelGGL(k_cb_plan, dim3((nblocks + 63) / 64), dim3(64), 0, s, (const uint8_t *)d_frame, (uint64_t)n, nbytes, blocksize, hdr->cbytes, ts, flags, plan, streams);
+    hipLaunchKernelGGL(k_cb_decode, dim3(nstreams < 2048u ? nstreams : 2048u), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target);
+    hb_prof_end(s);
+    if (filtered) {
+        hb_prof_begin("k_cb_unfilter", s);
+        if (unshuf)
+            hipLaunchKernelGGL(k_cb_unshuffle, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nbytes, blocksize, ts);
+        else
+            hipLaunchKernelGGL(k_cb_bitunshuffle, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nbytes, blocksize, ts);
+        hb_prof_end(s);
+    }
+    hipLaunchKernelGGL(k_cb_result, dim3(1), dim3(1), 0, s, plan, d_result, (uint64_t)nbytes);
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}
+
+}  // extern "C"

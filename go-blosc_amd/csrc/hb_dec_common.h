@@ -282,3 +282,154 @@ __device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh,
     return stop;
 }
 
+// ---- the serial block decoder (hb_lz4_dec.hip k_dec_serial; hb_cblosc.hip: one wavefront per stream of a C-Blosc-1 frame) ----
+#define SER_WIN   8192u
+#define SER_HIST  65536u
+#define SER_PAGE  32768u      // room for output between flushes
+#define SER_SOFT  16384u      // flush when the page holds this much
+
+// One LZ4 block, front to back, one wavefront (the body of k_dec_serial; also what decodes the streams of a C-Blosc-1 frame,
+// hb_cblosc.hip).  s_win: SER_WIN + 128 bytes, s_img: SER_HIST + SER_PAGE + 1024 bytes, s_tq: DTQ entries.  Returns the bytes
+// produced; err != 0: malformed (what lz4.UncompressBlock rejects) or more than cap bytes.
+__device__ __forceinline__ uint64_t dec_serial_core(const uint8_t *__restrict__ src, const uint64_t n_src, uint8_t *__restrict__ dst, const uint64_t cap,
+                                                    uint8_t *s_win, uint8_t *s_img, uint2 *s_tq, const int lane, int &err) {
+    bool fin = false;
+    err = 0;
+    uint8_t *out = s_img + SER_HIST;         // out[i], i in [-SER_HIST, SER_PAGE): output byte gbase + i
+    uint64_t gbase = 0;                      // output bytes already flushed to dst
+    uint32_t di = 0;                         // bytes in the page
+    uint64_t wpos = 0;                       // stream position of the window
+    uint32_t wlen = 0, wsh = 0;              // s_win[wsh + k] = src[wpos + k], k < wlen
+    uint64_t si = 0;                         // stream position
+
+    auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+        const uint8_t *g = src + at;
+        wsh = (uint32_t)((uintptr_t)g & 15u);
+        const uint64_t left = n_src - at;
+        wlen = (uint32_t)(left < (uint64_t)(SER_WIN - 16u) ? left : (uint64_t)(SER_WIN - 16u));
+        const u32x4 *ga = (const u32x4 *)(g - wsh);
+        const uint32_t nv = (wsh + wlen + 15u) >> 4;
+        wave_sync();
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+        wpos = at;
+        wave_sync();
+    };
+    // write the first fl (multiple of 16) page bytes to dst and slide the image down by fl
+    auto flush = [&](bool all) __attribute__((always_inline)) {
+        const uint32_t fl = all ? di : (di & ~15u);
+        if (fl == 0) return;
+        wave_sync();
+        uint8_t *o = dst + gbase;
+        for (uint32_t i = lane * 16u; i + 16u <= fl; i += 1024u) st16u(o + i, *(const u32x4 *)(out + i));
+        const uint32_t tail0 = fl & ~15u;
+        if (tail0 + lane < fl) o[tail0 + lane] = out[tail0 + lane];
+        if (!all) {
+            const uint32_t mv = SER_HIST + (di - fl);                 // bytes that stay: history + the unflushed tail
+            for (uint32_t k = lane * 16u; k < mv; k += 1024u) {       // ascending, 1 KiB per step: reads run ahead of writes
+                const u32x4 v = *(const u32x4 *)(s_img + fl + k);
+                *(u32x4 *)(s_img + k) = v;
+            }
+            wave_sync();
+        }
+        gbase += fl; di -= fl;
+    };
+
+    uint64_t lrem = 0, mrem = 0;             // literals / match bytes of the current sequence still to copy
+    uint32_t moff = 0, tok = 0;
+    int phase = 0;                           // 0 token, 1 literals, 2 offset + match length, 3 match
+    uint32_t nq = 0;
+    if (n_src) refill(0); else fin = true;
+    while (!err && !fin) {
+        if (gbase + di > cap) { err = 1; break; }              // before anything reaches dst
+        if (di >= SER_SOFT) flush(false);
+        const uint32_t room = SER_PAGE - di;
+        if (phase == 0) {
+            if (si == n_src) { fin = true; break; }                   // ran out of input at a token boundary: done
+            // keep a comfortable look-ahead in the window
+            if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+            uint32_t rel = (uint32_t)(si - wpos);
+            // ---- fast path: window-parallel parse, lane-parallel copies ----
+            const uint32_t hist = (uint32_t)(gbase < (uint64_t)SER_HIST ? gbase : (uint64_t)SER_HIST);
+            const bool stop = dec_fill(s_win, wsh, wlen, wlen, rel, nq, s_tq, lane);
+            bool rewound = false;
+            if (!dec_drain(s_win + wsh, 0, out, SER_PAGE, hist, di, rel, nq, s_tq, true, rewound, lane)) { err = 1; break; }
+            const bool moved = (wpos + rel) != si;
+            si = wpos + rel;
+            if (rewound) continue;                                    // page full: flush, then go on from that token
+            if (moved && !stop) continue;
+            if (si == n_src) { fin = true; break; }
+            if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src) continue;    // stopped at the window edge: refill first
+            // ---- one token the slow way (length extensions of any size, literal runs of any size) ----
+            if (si < wpos || si >= wpos + wlen) refill(si);
+            rel = (uint32_t)(si - wpos);
+            tok = __builtin_amdgcn_readfirstlane((uint32_t)s_win[wsh + rel]);   // uniform, but from a vector load
+            rel++;
+            uint32_t ll = tok >> 4;
+            if (ll == 15u) {
+                const uint64_t span = n_src - wpos;
+                if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { err = 1; break; }
+            }
+            si = wpos + rel;
+            lrem = ll;
+            phase = 1;
+            continue;
+        }
+        if (phase == 1) {
+            if (lrem) {
+                const uint32_t take = (uint32_t)(lrem < (uint64_t)room ? lrem : (uint64_t)room);
+                if (take == 0) { flush(false); continue; }
+                if ((uint64_t)take > n_src - si || gbase + di + take > cap) { err = 1; break; }
+                const uint8_t *g = src + si;
+                uint32_t k0 = 0;
+                for (; k0 + 4096u <= take; k0 += 4096u) {                // 4 x 16 B per lane in flight
+                    u32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = ld16u(g + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ((hb_u128u *)(out + di + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u))->v = v[q];
+                }
+                for (uint32_t k = k0 + lane; k < take; k += 64) out[di + k] = g[k];
+                si += take; di += take; lrem -= take;
+                continue;
+            }
+            if (si == n_src) {
+                if ((tok & 15u) != 0u) err = 1;                       // input ends after literals but a match was announced
+                fin = true;
+                break;
+            }
+            phase = 2;
+            continue;
+        }
+        if (phase == 2) {
+            if (n_src - si < 2) { err = 1; break; }
+            moff = __builtin_amdgcn_readfirstlane((uint32_t)src[si] | ((uint32_t)src[si + 1] << 8));
+            si += 2;
+            if (moff == 0) { err = 1; break; }
+            uint32_t ml = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u) {
+                if (si < wpos || si - wpos + 64u > wlen) refill(si);
+                uint32_t rel = (uint32_t)(si - wpos);
+                const uint64_t span = n_src - wpos;
+                if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ml, lane)) { err = 1; break; }
+                si = wpos + rel;
+            }
+            if ((uint64_t)moff > gbase + di) { err = 1; break; }      // before the start of the block (no dictionary)
+            mrem = ml;
+            phase = 3;
+            continue;
+        }
+        {   // phase 3: match, in pieces that fit the page
+            const uint32_t take = (uint32_t)(mrem < (uint64_t)room ? mrem : (uint64_t)room);
+            if (take == 0) { flush(false); continue; }
+            if (gbase + di + take > cap) { err = 1; break; }
+            wave_sync();
+            dec_match_copy(out, di, moff, take, lane);
+            di += take; mrem -= take;
+            if (mrem == 0) phase = 0;
+        }
+    }
+    if (!err && gbase + di > cap) err = 1;
+    if (!err) flush(true);
+    return gbase + di;
+}
+

@@ -21,24 +21,16 @@
 // Whatever is wrong with the stream (offset 0, offset before the start of the block) only raises SyPlan.fail: the single wavefront
 // then decodes and reports what lz4.UncompressBlock reports.  A block that passes is decoded to exactly the bytes the serial
 // decoder produces -- every output byte is written from the same source by the same rule, only in a different order.
-#include "hb_lz4_region.h"
+#include "hb_sym_decode.h"
 
 #define SY_W        65536u        // entries of a tail map / bytes of a tail image (index = distance 1..65535; entry 0 unused)
 #define SY_GROUPS   128u          // groups of regions in pass B
-#define SY_IMG      4096u         // bytes of output a wave holds in LDS: the last SY_HIST bytes it wrote to HBM + what it is building
-#define SY_HIST     2048u
 #define SY_SUB      8u            // a region with more than SY_HEAVY bytes of output is decoded in this many parts
 #define SY_HEAVY    (1u << 20)
 #define SY_MAXUNITS (RG_MAXREG * SY_SUB)
 #define SY_PIECE    (256u << 10)  // bytes of a region one workgroup resolves at a time (k_sy_resolve)
-#define SY_NCAP     64u           // tile-to-tile copies up to this long are done by their own lane
-#define SY_BIG      (256u << 10)  // literal runs / matches from this size on are copied by the whole chip (k_sy_big)
 #define SY_ROUNDS   3             // launches of pass A; the last one copies everything inline
 
-struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact; uint32_t pad[9]; };   // per: units WITH OUTPUT per group of pass B
-// what one wavefront of pass A decodes: a region of the token discovery, or one of SY_SUB parts of a region whose output is large
-struct SyUnit { uint32_t entry, exit, opos, outlen, rtp, rout, state, pad; };   // state: bit 0 done, bit 1 / 2: literals / match of token rtp copied
-struct SyBig { uint32_t kind, dst, src, len, O, pad[3]; };          // kind 0: literals from stream position src; 1: match, src = offset
 struct SyLayout { size_t plan, par, units, list, big, items, sym, maps, tails, total; };
 static inline uint32_t sy_max_groups(size_t n_out) {
     const size_t units_max = (hb_lz4_bound(n_out) / RG_MINREG + 1) * SY_SUB;       // a block of n_out bytes is at most this long
@@ -61,206 +53,6 @@ static inline SyLayout sy_layout(size_t n_out) {
     return L;
 }
 size_t hb_lz4_sym_workspace(size_t n_out) { return sy_layout(n_out).total; }
-
-// every store of this wave so far has reached the cache all lanes of the CU read through, and later loads are not started early
-__device__ __forceinline__ void sy_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// ---- copies of pass A.  D = output values, S = references (u16 per output byte; Sb = the same as bytes), O = first output byte of
-// the region.  A load through HBM/L2 costs a microsecond, so every copy issues ALL its loads before its first store (the compiler
-// cannot do that: for all it knows they alias), and pieces are placed so that no store is partial: the last piece of a copy is
-// moved back to end exactly at the end (it rewrites a few bytes with the same values). ----
-
-// ---- the output image.  A wave keeps the last SY_IMG bytes of its output in LDS (values s_d, references s_s): what it is building,
-// behind SY_HIST bytes of what it has written to HBM already.  Matches that copy what the image holds -- the short offsets, and the
-// chains of matches that each copy the one before -- run LDS to LDS in cheap dependency rounds; only sources in front of the image
-// ("far") are fetched from HBM, all lanes at once, before the rounds start (nothing in the batch can change them). ----
-
-// What one lane brings into the image from HBM: the `far` first bytes of its match, whose source out[sp...) lies in front of the image,
-// to image[tf...).  Lengths come in three classes (8-byte pieces, two 4-byte pieces, single bytes) and the lanes of a wave are in
-// all of them at once: every class issues its loads before any class stores, so the wave pays ONE round trip, not three.  More
-// than 32 bytes: 32 per further round trip.
-__device__ __forceinline__ void sy_fetch_lane(const uint8_t *D, const uint16_t *S, uint8_t *s_d, uint16_t *s_s, uint32_t tf, uint32_t sp, uint32_t far, const uint32_t O) {
-    const uint8_t *Sb = (const uint8_t *)S;
-    uint8_t *s_sb = (uint8_t *)s_s;
-    {   // bytes from in front of the region are references: nothing to load
-        const uint32_t nctx = sp < O ? (O - sp < far ? O - sp : far) : 0u;
-        for (uint32_t k = 0; k < nctx; k++) s_s[tf + k] = (uint16_t)(O - sp - k);
-        tf += nctx; sp += nctx; far -= nctx;
-    }
-    const bool f8 = far >= 8u, f4 = far >= 4u && far < 8u, f1 = far != 0u && far < 4u;
-    uint64_t fv[4]; u32x4 fa[4]; uint32_t fk[4];
-    uint32_t fw0 = 0, fw1 = 0; uint64_t fb0 = 0, fb1 = 0;
-    uint8_t fx[3]; uint16_t fy[3];
-    // ---- loads ----
-    if (f8) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) { fk[c] = 8u * c; if (fk[c] < far) { if (fk[c] + 8u > far) fk[c] = far - 8u; fv[c] = ld8u(D + sp + fk[c]); fa[c] = ld16u(Sb + 2u * (size_t)(sp + fk[c])); } }
-    }
-    if (f4) { fw0 = ld4u(D + sp); fw1 = ld4u(D + sp + far - 4u); fb0 = ld8u(Sb + 2u * (size_t)sp); fb1 = ld8u(Sb + 2u * (size_t)(sp + far - 4u)); }
-    if (f1) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) if ((uint32_t)k < far) { fx[k] = D[sp + k]; fy[k] = S[sp + k]; }
-    }
-    // ---- stores ----
-    if (f8) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) if (8u * c < far) { ((hb_u64u *)(s_d + tf + fk[c]))->v = fv[c]; ((hb_u128u *)(s_sb + 2u * (tf + fk[c])))->v = fa[c]; }
-    }
-    if (f4) {
-        ((hb_u32u *)(s_d + tf))->v = fw0; ((hb_u32u *)(s_d + tf + far - 4u))->v = fw1;
-        ((hb_u64u *)(s_sb + 2u * tf))->v = fb0; ((hb_u64u *)(s_sb + 2u * (tf + far - 4u)))->v = fb1;
-    }
-    if (f1) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) if ((uint32_t)k < far) { s_d[tf + k] = fx[k]; s_s[tf + k] = fy[k]; }
-    }
-    // ---- beyond 32 bytes ----
-    for (uint32_t blk = 32u; blk < far; blk += 32u) {
-        uint64_t v[4]; u32x4 a[4]; uint32_t k[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            k[c] = blk + 8u * c;
-            if (k[c] < far) { if (k[c] + 8u > far) k[c] = far - 8u; v[c] = ld8u(D + sp + k[c]); a[c] = ld16u(Sb + 2u * (size_t)(sp + k[c])); }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) if (blk + 8u * c < far) { ((hb_u64u *)(s_d + tf + k[c]))->v = v[c]; ((hb_u128u *)(s_sb + 2u * (tf + k[c])))->v = a[c]; }
-    }
-}
-// the same by the whole wave (len > 64)
-__device__ __forceinline__ void sy_far_wave(const uint8_t *D, const uint16_t *S, uint8_t *s_d, uint16_t *s_s, uint32_t t, uint32_t sp, uint32_t len, const uint32_t O, const int lane) {
-    const uint32_t nctx = sp < O ? (O - sp < len ? O - sp : len) : 0u;
-    for (uint32_t i = lane; i < nctx; i += 64) s_s[t + i] = (uint16_t)(O - sp - i);
-    t += nctx; sp += nctx; len -= nctx;
-    const uint8_t *Sb = (const uint8_t *)S;
-    uint8_t *s_sb = (uint8_t *)s_s;
-    if (len < 16u) { if ((uint32_t)lane < len) { s_d[t + lane] = D[sp + lane]; s_s[t + lane] = S[sp + lane]; } return; }
-    for (uint32_t blk = 0; blk < len; blk += 4096u) {
-        u32x4 v[4], a[4], b[4]; uint32_t j[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            j[q] = blk + (uint32_t)q * 1024u + (uint32_t)lane * 16u;
-            if (j[q] < len) {
-                if (j[q] + 16u > len) j[q] = len - 16u;
-                v[q] = ld16u(D + sp + j[q]); a[q] = ld16u(Sb + 2u * (size_t)(sp + j[q])); b[q] = ld16u(Sb + 2u * (size_t)(sp + j[q]) + 16u);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (blk + (uint32_t)q * 1024u + (uint32_t)lane * 16u < len) {
-                ((hb_u128u *)(s_d + t + j[q]))->v = v[q]; ((hb_u128u *)(s_sb + 2u * (t + j[q])))->v = a[q]; ((hb_u128u *)(s_sb + 2u * (t + j[q]) + 16u))->v = b[q];
-            }
-    }
-}
-// literals: staged stream window (LDS) -> image; values, never references
-__device__ __forceinline__ void sy_lits_img_lane(uint8_t *s_d, uint16_t *s_s, const uint32_t t, const uint8_t *lp, const uint32_t lit) {
-    lds_copy_exact(s_d + t, lp, lit);
-    uint8_t *z = (uint8_t *)(s_s + t);
-    uint32_t k = 0;
-    for (; k + 8u <= 2u * lit; k += 8u) ((hb_u64u *)(z + k))->v = 0ull;
-    if ((2u * lit) & 4u) { ((hb_u32u *)(z + k))->v = 0u; k += 4u; }
-    if ((2u * lit) & 2u) ((hb_u16u *)(z + k))->v = 0;
-}
-__device__ __forceinline__ void sy_lits_img_wave(uint8_t *s_d, uint16_t *s_s, const uint32_t t, const uint8_t *lp, const uint32_t lit, const int lane) {
-    for (uint32_t k = lane; k < lit; k += 64) { s_d[t + k] = lp[k]; s_s[t + k] = 0; }
-}
-// near copies: tile[md + k] = tile[md - off + k], values and references alike.  One lane (what lds_match_lane does for bytes):
-__device__ __forceinline__ void sy_near_lane(uint8_t *s_d, uint16_t *s_s, const uint32_t md, const uint32_t off, const uint32_t len) {
-    lds_match_lane(s_d, md, off, len);
-    uint16_t *d = s_s + md;
-    const uint16_t *s = d - off;
-    uint32_t k = 0;
-    if (off >= 4u) for (; k + 4u <= len; k += 4u) ((hb_u64u *)(d + k))->v = ((const hb_u64u *)(s + k))->v;
-    for (; k < len; k++) d[k] = s[k];
-}
-// ... and the whole wave
-__device__ __forceinline__ void sy_near_wave(uint8_t *s_d, uint16_t *s_s, const uint32_t md, const uint32_t off, const uint32_t len, const int lane) {
-    dec_match_copy(s_d, md, off, len, lane);
-    if (off >= 64u || off >= len) {
-        for (uint32_t i = lane; i < len; i += 64) s_s[md + i] = s_s[md + i - off];
-    } else {
-        uint32_t m = (uint32_t)lane % off;
-        const uint32_t step = 64u % off;
-        for (uint32_t i = lane; i < len; i += 64) {
-            s_s[md + i] = s_s[md - off + m];
-            m += step; if (m >= off) m -= off;
-        }
-    }
-}
-__device__ __forceinline__ void sy_lits_wave(uint8_t *D, uint16_t *S, const uint32_t d0, const uint8_t *g, const uint32_t lit, const int lane) {
-    uint8_t *Sb = (uint8_t *)S;
-    u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-    if (lit < 16u) { if ((uint32_t)lane < lit) { D[d0 + lane] = g[lane]; S[d0 + lane] = 0; } return; }
-    for (uint32_t blk = 0; blk < lit; blk += 4096u) {
-        u32x4 v[4]; uint32_t j[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            j[q] = blk + (uint32_t)q * 1024u + (uint32_t)lane * 16u;
-            if (j[q] < lit) { if (j[q] + 16u > lit) j[q] = lit - 16u; v[q] = ld16u(g + j[q]); }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (blk + (uint32_t)q * 1024u + (uint32_t)lane * 16u < lit) { st16u(D + d0 + j[q], v[q]); st16u(Sb + 2u * (size_t)(d0 + j[q]), z); st16u(Sb + 2u * (size_t)(d0 + j[q]) + 16u, z); }
-    }
-}
-// out[md + i] = out[s0 + i], i < len, the whole wave, source and destination do not overlap (len <= md - s0)
-__device__ __forceinline__ void sy_copy_wave(uint8_t *D, uint16_t *S, const uint32_t md, const uint32_t s0, const uint32_t len, const uint32_t O, const int lane) {
-    const uint32_t nctx = s0 < O ? (O - s0 < len ? O - s0 : len) : 0u;          // leading bytes that come from in front of the region
-    for (uint32_t i = lane; i < nctx; i += 64) S[md + i] = (uint16_t)(O - s0 - i);
-    uint8_t *Sb = (uint8_t *)S;
-    const uint32_t n = len - nctx, d = md + nctx, s = s0 + nctx;
-    if (n < 16u) {
-        if ((uint32_t)lane < n) { const uint8_t v = D[s + lane]; const uint16_t a = S[s + lane]; D[d + lane] = v; S[d + lane] = a; }
-        return;
-    }
-    for (uint32_t blk = 0; blk < n; blk += 4096u) {
-        u32x4 v[4], a[4], b[4]; uint32_t j[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            j[q] = blk + (uint32_t)q * 1024u + (uint32_t)lane * 16u;
-            if (j[q] < n) {
-                if (j[q] + 16u > n) j[q] = n - 16u;
-                v[q] = ld16u(D + s + j[q]); a[q] = ld16u(Sb + 2u * (size_t)(s + j[q])); b[q] = ld16u(Sb + 2u * (size_t)(s + j[q]) + 16u);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (blk + (uint32_t)q * 1024u + (uint32_t)lane * 16u < n) {
-                st16u(D + d + j[q], v[q]); st16u(Sb + 2u * (size_t)(d + j[q]), a[q]); st16u(Sb + 2u * (size_t)(d + j[q]) + 16u, b[q]);
-            }
-    }
-}
-// a whole match by the whole wave.  Overlapping (off < mlen: the `off` bytes in front of it, repeated): the first 128..256 bytes are
-// gathered byte by byte from that period, then pieces that double -- what is copied already is source for the next piece -- so a run
-// of any length and period costs 1 + log2(length / 256) round trips.
-__device__ __forceinline__ void sy_match_wave(uint8_t *D, uint16_t *S, const uint32_t md, const uint32_t off, const uint32_t mlen, const uint32_t O, const int lane) {
-    const uint32_t s0 = md - off;
-    uint32_t done = 0;
-    if (off < mlen && off < 256u) {
-        const uint32_t reps = 256u / off;
-        const uint32_t P = off * reps < mlen ? off * reps : mlen;      // (a multiple of the period unless it is the whole match)
-        uint8_t v[4]; uint16_t a[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t k = (uint32_t)lane + 64u * q;
-            if (k < P) { const uint32_t sp = s0 + k % off; if (sp >= O) { v[q] = D[sp]; a[q] = S[sp]; } else { v[q] = 0; a[q] = (uint16_t)(O - sp); } }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const uint32_t k = (uint32_t)lane + 64u * q; if (k < P) { D[md + k] = v[q]; S[md + k] = a[q]; } }
-        done = P;
-        if (done < mlen) sy_sync();
-    }
-    while (done < mlen) {
-        const uint32_t room = off + done, left = mlen - done;
-        const uint32_t piece = left < room ? left : room;               // `done` stays a multiple of the period until the last piece
-        sy_copy_wave(D, S, md + done, s0, piece, O, lane);
-        done += piece;
-        if (done < mlen) sy_sync();
-    }
-}
 
 // go: the token chain is verified and nothing has decoded the block yet
 __global__ void k_sy_gate(const RgPlan *rg, const DecPlan *dp, SyPlan *sy, uint32_t groups, uint32_t per) {
@@ -355,7 +147,6 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
     if (!sy->go || sy->fail) return;
     const int lane = threadIdx.x;
     const uint32_t nact = sy->nact;
-    uint8_t *Sb = (uint8_t *)S;
     for (uint32_t i = blockIdx.x; i < nact; i += gridDim.x) {
         SyUnit *R = un + list[i];
         const uint32_t entry = RFL(R->entry), exitp = RFL(R->exit);
@@ -366,163 +157,10 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
         const uint32_t rtp = RFL(R->rtp);
         const uint32_t start = rtp ? rtp : entry;
         uint32_t out = rtp ? RFL(R->rout) : O;         // next output byte
-        // the image: s_d[i] / s_s[i] = output byte ib + i for i < out - ib; bytes below fl are in HBM already (history kept for near copies)
-        uint32_t ib = out, fl = out;
-        bool bad = false, parked = false, unsynced = false;
-        // the new part of the image goes to HBM
-        auto flush = [&]() __attribute__((always_inline)) {
-            const uint32_t n = out - fl;
-            if (n == 0u) return;
-            wave_sync();
-            const uint32_t o = fl - ib;
-            const uint8_t *s_sb = (const uint8_t *)s_s;
-            if (n < 16u) {
-                if ((uint32_t)lane < n) { D[fl + lane] = s_d[o + lane]; S[fl + lane] = s_s[o + lane]; }
-            } else {
-                for (uint32_t i = (uint32_t)lane * 16u; i < n; i += 1024u) {
-                    const uint32_t j = i + 16u <= n ? i : n - 16u;
-                    st16u(D + fl + j, ((const hb_u128u *)(s_d + o + j))->v);
-                    st16u(Sb + 2u * (size_t)(fl + j), ((const hb_u128u *)(s_sb + 2u * (o + j)))->v);
-                    st16u(Sb + 2u * (size_t)(fl + j) + 16u, ((const hb_u128u *)(s_sb + 2u * (o + j) + 16u))->v);
-                }
-            }
-            fl = out;
-            unsynced = true;                                             // far loads must wait for these stores (sy_sync), not the flush itself
-        };
-        // make room: flush, keep the last SY_HIST bytes as history at the bottom of the image
-        auto slide = [&]() __attribute__((always_inline)) {
-            flush();
-            const uint32_t have = out - ib, keep = have < SY_HIST ? have : SY_HIST, delta = have - keep;
-            if (delta) {
-                uint8_t *s_sb = (uint8_t *)s_s;
-                wave_sync();
-                for (uint32_t k = (uint32_t)lane * 16u; k < keep; k += 1024u) {          // ascending: a step's reads are done before its writes
-                    const u32x4 v = ((const hb_u128u *)(s_d + delta + k))->v;
-                    ((hb_u128u *)(s_d + k))->v = v;
-                }
-                for (uint32_t k = (uint32_t)lane * 16u; k < 2u * keep; k += 1024u) {
-                    const u32x4 v = ((const hb_u128u *)(s_sb + 2u * delta + k))->v;
-                    ((hb_u128u *)(s_sb + k))->v = v;
-                }
-                wave_sync();
-            }
-            ib = out - keep;
-        };
-        auto batch = [&](uint32_t cnt, uint32_t tp, uint32_t ls, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t lp) __attribute__((always_inline)) -> bool {
-            (void)tp; (void)ls;
-            const bool tok = (uint32_t)lane < cnt;
-            const uint32_t olen = tok ? lit + mlen : 0u;
-            const uint32_t incl = wave_incl_scan_dpp(olen);
-            const uint32_t d0 = out + incl - olen, md = d0 + lit;
-            if (hb_ballot(tok && (off == 0u || off > md))) { bad = true; return false; }     // offset 0 / before the start of the block
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-            // what a lane fetches from HBM itself (32 bytes per round trip): up to four times the batch's average, 64 at least
-            const uint32_t thr = total < 64u * 16u ? 64u : (total > 1024u * 16u ? 1024u : total >> 4);
-            const uint32_t s0 = md - off;
-            const uint32_t end_all = out + total;
-            uint32_t lo = 0;
-            while (lo < cnt) {
-                const unsigned long long over = hb_ballot(tok && (uint32_t)lane >= lo && d0 + olen - ib > SY_IMG);
-                const uint32_t hi = over ? (uint32_t)__builtin_ctzll(over) : cnt;
-                if (hi == lo) {
-                    // the next sequence does not fit into what is left of the image
-                    const uint32_t ol = __builtin_amdgcn_readlane(olen, (int)lo);
-                    if (ol > SY_IMG - SY_HIST) {                          // nor behind the history alone: straight in HBM, the whole wave
-                        flush();
-                        sy_sync(); unsynced = false;
-                        const uint32_t dl = __builtin_amdgcn_readlane(d0, (int)lo), ll = __builtin_amdgcn_readlane(lit, (int)lo);
-                        if (ll) { sy_lits_wave(D, S, dl, src + __builtin_amdgcn_readlane(ls, (int)lo), ll, lane); sy_sync(); }
-                        sy_match_wave(D, S, dl + ll, __builtin_amdgcn_readlane(off, (int)lo), __builtin_amdgcn_readlane(mlen, (int)lo), O, lane);
-                        sy_sync();
-                        out = dl + ol; ib = out; fl = out;
-                        lo++;
-                    } else slide();
-                    continue;
-                }
-                const bool act = tok && (uint32_t)lane >= lo && (uint32_t)lane < hi;
-                const uint32_t t0 = d0 - ib, tm = md - ib;
-                // literals: from the staged stream window
-                if (act && lit <= 32u) sy_lits_img_lane(s_d, s_s, t0, s_win + lp, lit);
-                unsigned long long lm = hb_ballot(act && lit > 32u);
-                while (lm) {
-                    const int l = __builtin_ctzll(lm);
-                    sy_lits_img_wave(s_d, s_s, __builtin_amdgcn_readlane(t0, l), s_win + __builtin_amdgcn_readlane(lp, l), __builtin_amdgcn_readlane(lit, l), lane);
-                    lm &= lm - 1;
-                }
-                // the part of every match whose source lies in front of the image: from HBM, all lanes at once (nothing in the batch can
-                // change those bytes)
-                const uint32_t farlen = (act && s0 < ib) ? (ib - s0 < mlen ? ib - s0 : mlen) : 0u;
-                if (hb_ballot(farlen != 0u)) {
-                    if (unsynced) { sy_sync(); unsynced = false; }
-                    sy_fetch_lane(D, S, s_d, s_s, tm, s0, farlen <= thr ? farlen : 0u, O);
-                    lm = hb_ballot(farlen > thr);
-                    while (lm) {
-                        const int l = __builtin_ctzll(lm);
-                        sy_far_wave(D, S, s_d, s_s, __builtin_amdgcn_readlane(tm, l), __builtin_amdgcn_readlane(s0, l), __builtin_amdgcn_readlane(farlen, l), O, lane);
-                        lm &= lm - 1;
-                    }
-                }
-                // the rest of every match copies what the image holds: dependency rounds in LDS (the rule of dec_drain, hb_dec_common.h: a
-                // match is ready when its source ends before the first pending match, or starts at / after the end of the nearest
-                // pending match in front of it)
-                const uint32_t nlen = act ? mlen - farlen : 0u, nmd = tm + farlen;
-                const uint32_t srcs = nmd - off, srcend = srcs + (nlen < off ? nlen : off), mend = nmd + nlen;
-                unsigned long long pend = hb_ballot(nlen != 0u);
-                while (pend) {
-                    const int f = __builtin_ctzll(pend);
-                    const uint32_t X = __builtin_amdgcn_readlane(nmd, f);
-                    const uint32_t nlf = __builtin_amdgcn_readlane(nlen, f);
-                    if (nlf > SY_NCAP) {
-                        sy_near_wave(s_d, s_s, X, __builtin_amdgcn_readlane(off, f), nlf, lane);
-                        pend &= pend - 1;
-                        continue;
-                    }
-                    const unsigned long long below = pend & ((1ull << lane) - 1ull);
-                    const uint32_t pj = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-                    const uint32_t pe = (uint32_t)__shfl((int)mend, (int)pj);
-                    const bool ready = ((pend >> lane) & 1ull) && nlen <= SY_NCAP && (srcend <= X || below == 0ull || srcs >= pe);
-                    if (ready) sy_near_lane(s_d, s_s, nmd, off, nlen);
-                    pend &= ~hb_ballot(ready);
-                }
-                out = hi == cnt ? end_all : __builtin_amdgcn_readlane(d0, (int)hi);
-                lo = hi;
-            }
-            return true;
-        };
-        auto park = [&](uint32_t tp, uint32_t flags, uint32_t kind, uint32_t dst, uint32_t a, uint32_t len) __attribute__((always_inline)) {
-            if (lane == 0) {
-                const uint32_t slot = atomicAdd(&sy->nbig, 1u);             // (at most one per region and launch: nreg slots)
-                SyBig b; b.kind = kind; b.dst = dst; b.src = a; b.len = len; b.O = O; b.pad[0] = b.pad[1] = b.pad[2] = 0;
-                big[slot] = b;
-                R->rtp = tp; R->rout = out; R->state = flags;
-            }
-            parked = true;
-        };
-        // sequences the window parser leaves alone (lengths of KiB and more, the edges of the staged window): straight in HBM
-        auto single = [&](uint32_t tp, uint32_t ls, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t tok) __attribute__((always_inline)) -> bool {
-            if (mlen == 0u && (tok & 15u) != 0u) { bad = true; return false; }        // the input ends after literals but a match was announced
-            flush();
-            sy_sync(); unsynced = false;
-            const uint32_t have = (tp == rtp) ? (st >> 1) : 0u;                 // what earlier launches did of this token
-            if (lit && !(have & 1u)) {
-                if (lit >= SY_BIG && !last) { park(tp, 2u, 0u, out, ls, lit); return false; }
-                sy_lits_wave(D, S, out, src + ls, lit, lane);
-            }
-            const uint32_t md = out + lit;
-            if (mlen && !(have & 2u)) {
-                if (off == 0u || off > md) { bad = true; return false; }
-                if (mlen >= SY_BIG && !last) { park(tp, 2u | 4u, 1u, md, off, mlen); return false; }
-                sy_sync();
-                sy_match_wave(D, S, md, off, mlen, O, lane);
-            }
-            out = md + mlen; ib = out; fl = out;
-            sy_sync();
-            return true;
-        };
-        const bool ok = rg_walk(src, n_src, start, exitp, s_win, s_tq, lane, batch, single);
+        bool parked;
+        const bool ok = sy_decode_unit<true>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen));
         if (!parked) {
-            flush();
-            if ((!ok || bad || out != O + RFL(R->outlen)) && lane == 0) atomicExch(&sy->fail, 1u);
+            if ((!ok || out != O + RFL(R->outlen)) && lane == 0) atomicExch(&sy->fail, 1u);
             if (lane == 0) R->state = 1u;
         }
         wave_sync();

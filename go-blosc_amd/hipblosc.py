@@ -88,7 +88,8 @@ EXPORTS = [
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace", "hb_decompress_frame_workspace_foreign", "hb_lz4_decompress_workspace_foreign",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
-    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_queue_create", "hb_queue_create_ex", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
+    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_cblosc_parse_header", "hb_cblosc_decompress", "hb_cblosc_decompress_workspace", "hb_cblosc_decompress_dev",
+    "hb_queue_create", "hb_queue_create_ex", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
 
 
@@ -144,6 +145,8 @@ def lib():
             "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
             "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),
             "hb_debug_decode_fusion": (None, [i32]), "hb_debug_plane_mask": (None, [u32]),
+            "hb_cblosc_parse_header": (i32, [vp, sz, vp]), "hb_cblosc_decompress": (i64, [vp, sz, vp, sz, i32]),
+            "hb_cblosc_decompress_workspace": (sz, [sz, sz, sz]), "hb_cblosc_decompress_dev": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, vp]),
             "hb_queue_create": (vp, [i32, i32, sz]), "hb_queue_create_ex": (vp, [i32, i32, sz, ctypes.c_uint]), "hb_queue_destroy": (None, [vp]),
             "hb_queue_compress": (i64, [vp, vp, sz, vp, sz, i32, i32, i32, i32, u32]),
             "hb_queue_decompress": (i64, [vp, vp, sz, vp, sz, i32]),
@@ -437,3 +440,25 @@ class FrameQueue:
 
     def __del__(self):
         self.close()
+
+
+# ---- frames in the C-Blosc-1 wire format (decode only; LZ4 / LZ4HC streams and memcpyed frames) ----
+class CBloscHeader(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_uint8), ("versionlz", ctypes.c_uint8), ("flags", ctypes.c_uint8), ("typesize", ctypes.c_uint8),
+                ("nbytes", ctypes.c_uint32), ("blocksize", ctypes.c_uint32), ("cbytes", ctypes.c_uint32), ("codec_format", ctypes.c_uint32)]
+
+
+def CBloscParseHeader(frame):
+    p, n, keep = _buf(frame)
+    h = CBloscHeader()
+    _check(lib().hb_cblosc_parse_header(p, n, ctypes.byref(h)))
+    return h
+
+
+def CBloscDecompress(frame):
+    """What blosc_decompress() of c-blosc 1.x returns for `frame` (include/hipblosc.h hb_cblosc_decompress)."""
+    p, n, keep = _buf(frame)
+    h = CBloscParseHeader(frame)
+    out = ctypes.create_string_buffer(max(h.nbytes, 1))
+    rc = _check(lib().hb_cblosc_decompress(p, n, ctypes.cast(out, ctypes.c_void_p), h.nbytes, device))
+    return out.raw[:rc]

@@ -220,6 +220,23 @@ int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst,
  * for the newest 4 * depth such tickets; older ones answer HB_ERR_BAD_ARG. */
 int64_t hb_queue_wait(hb_queue *q, int64_t ticket);
 
+/* ---- frames in the C-Blosc-1 wire format (c-blosc 1.x: bstarts table, blocks split into `typesize` streams, the
+ *      filter per block) -- what go-blosc's README.md:20 claims to be compatible with and blosc.go does not implement.  Decoding
+ *      only, codec formats LZ4 / LZ4HC and memcpyed frames; byte shuffle, bit shuffle or none, any typesize.  Not a seam of the
+ *      reference (it has none for this): an extension next to hb_decompress_frame. ---- */
+typedef struct hb_cblosc_header {
+    uint8_t  version, versionlz, flags, typesize;   /* flags: 0x01 shuffle, 0x02 memcpyed, 0x04 bitshuffle, 0x10 not split */
+    uint32_t nbytes, blocksize, cbytes;
+    uint32_t codec_format;                          /* flags >> 5: 0 blosclz, 1 lz4 / lz4hc, 2 snappy, 3 zlib, 4 zstd */
+} hb_cblosc_header;
+int     hb_cblosc_parse_header(const void *frame, size_t n, hb_cblosc_header *out);          /* host-only */
+size_t  hb_cblosc_decompress_workspace(size_t nbytes, size_t blocksize, size_t typesize);
+int     hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, size_t n, void *d_dst, size_t cap,
+                                 void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+/* host pointers: returns the decoded bytes (== nbytes of the header) or HB_ERR_*: HB_ERR_INVALID_CODEC for the codec formats
+ * that are not LZ4, HB_ERR_DECOMPRESSION_FAILED for anything blosc_decompress() answers with a negative number */
+int64_t hb_cblosc_decompress(const void *frame, size_t n, void *dst, size_t cap, int device);
+
 #ifdef __cplusplus
 }
 #endif
