@@ -559,6 +559,26 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     return (int64_t)r.bytes;
 }
 
+int64_t hb_cblosc_compress(const void *src, size_t n, void *dst, size_t cap, int shuffle, int typesize, int device) {
+    if ((!src && n) || !dst) return HB_ERR_BAD_ARG;
+    if (typesize < 1 || typesize > 255 || shuffle < 0 || shuffle > 2) return HB_ERR_BAD_ARG;
+    int rc = select_device(device);
+    if (rc) return rc;
+    Scratch sc(device);
+    const size_t fb = hb_cblosc_bound(n, typesize), wb = hb_cblosc_compress_workspace(n, shuffle, typesize);
+    uint8_t *d_src = sc.get(n + 64), *d_frame = sc.get(fb + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
+    if (!d_src || !d_frame || !d_work || !d_res) return HB_ERR_HIP;
+    if (n) HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
+    rc = hb_cblosc_compress_dev(d_src, n, d_frame, fb + 64, shuffle, typesize, d_work, wb, (hb_result *)d_res, nullptr);
+    if (rc) return rc;
+    hb_result r;
+    HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
+    if (r.status) return r.status;
+    if (r.bytes > cap) return HB_ERR_SHORT_BUFFER;
+    HB_HIP_TRY(hipMemcpy(dst, d_frame, r.bytes, hipMemcpyDeviceToHost));
+    return (int64_t)r.bytes;
+}
+
 int64_t hb_cblosc_decompress(const void *frame, size_t n, void *dst, size_t cap, int device) {
     hb_cblosc_header h;
     int rc = hb_cblosc_parse_header(frame, n, &h);

@@ -134,6 +134,159 @@ __global__ void k_cb_result(const CbPlan *plan, hb_result *result, uint64_t nbyt
 }
 __global__ void k_cb_init(CbPlan *plan) { plan->fail = 0; }
 
+// =====================================================================================================================
+// Writing the format.  A stream has to be ONE LZ4 block, and this library's encoder makes blocks of 4 KiB chunks that are
+// stitched afterwards -- so the frame is laid out such that nothing needs stitching: blocksize = 4096 x typesize when the
+// block is split (typesize <= 16 and a filter is on), else 4096 with the not-split flag; then every stream is exactly one
+// matcher chunk, encoded as a block of its own (match_chunk MODE 2).  The filters run per block first (k_cb_shuffle /
+// k_cb_bitshuffle, the mirrors of the kernels above), a stream that does not shrink is stored (cbytes == its size, like
+// blosc_c), the last, shorter block is one stored stream.  Ratio = the chunk-local encoder's + 4 bytes per stream.
+// =====================================================================================================================
+struct CbEncPlan { uint32_t total, pad[3]; };
+
+__global__ void k_cb_shuffle(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t nbytes, uint32_t blocksize, uint32_t ts) {
+    const uint32_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const uint32_t per = blocksize / ts + 1u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)nblocks * per; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i / per), e = (uint32_t)(i % per);
+        const uint32_t base = b * blocksize, bsize = nbytes - base < blocksize ? nbytes - base : blocksize, nel = bsize / ts;
+        if (e < nel) {
+            const uint8_t *s = src + base + (size_t)e * ts;
+            uint8_t *d = dst + base + e;
+            for (uint32_t j = 0; j < ts; j++) d[(size_t)j * nel] = s[j];
+        } else if (e == nel) {
+            for (uint32_t k = nel * ts; k < bsize; k++) dst[base + k] = src[base + k];
+        }
+    }
+}
+__global__ void k_cb_bitshuffle(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t nbytes, uint32_t blocksize, uint32_t ts) {
+    const uint32_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const uint32_t per = blocksize / (8u * ts) + 1u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)nblocks * per; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i / per), g = (uint32_t)(i % per);
+        const uint32_t base = b * blocksize, bsize = nbytes - base < blocksize ? nbytes - base : blocksize, nel = bsize / ts;
+        if (nel % 8u != 0u) { for (uint32_t k = g; k < bsize; k += per) dst[base + k] = src[base + k]; continue; }
+        const uint32_t ng = nel / 8u;
+        if (g < ng) {
+            for (uint32_t j = 0; j < ts; j++) {
+                uint64_t x = 0;                                                         // byte e = byte j of element 8 g + e
+                for (uint32_t e = 0; e < 8u; e++) x |= (uint64_t)src[base + (size_t)(8u * g + e) * ts + j] << (8u * e);
+                uint64_t t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x ^= t ^ (t << 7);
+                t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
+                t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
+                for (uint32_t k = 0; k < 8u; k++) dst[base + (size_t)(8u * j + k) * ng + g] = (uint8_t)(x >> (8u * k));
+            }
+        } else if (g == ng) {
+            for (uint32_t k = nel * ts; k < bsize; k++) dst[base + k] = src[base + k];
+        }
+    }
+}
+
+struct CbChunkDesc { uint32_t lead, enc_len, last_end, mcode0; };       // = ChunkDesc of hb_lz4_enc.hip
+// bytes of stream c in the frame: 4 + the block, or 4 + the chunk itself when the block is no smaller
+__device__ __forceinline__ uint32_t cb_stream_bytes(const CbChunkDesc &d) { return 4u + (d.enc_len < HB_CHUNK ? d.enc_len : HB_CHUNK); }
+// exclusive prefix sum of the stream sizes, 1024 chunks per tile: tile sums, one workgroup over the tiles, offsets
+__global__ __launch_bounds__(256) void k_cbe_tiles(const CbChunkDesc *__restrict__ desc, uint32_t nchunks, uint32_t *__restrict__ tile_sum) {
+    __shared__ uint32_t s[256];
+    const uint32_t t0 = blockIdx.x * 1024u;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < 4u; k++) { const uint32_t c = t0 + k * 256u + threadIdx.x; if (c < nchunks) sum += cb_stream_bytes(desc[c]); }
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(1024) void k_cbe_scan(uint32_t *tile_sum, uint32_t ntiles, CbEncPlan *plan) {
+    __shared__ uint32_t s[1024];
+    const int t = threadIdx.x;
+    // (ntiles <= 1024: inputs below 4 GiB)
+    const uint32_t v = (uint32_t)t < ntiles ? tile_sum[t] : 0u;
+    s[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const uint32_t y = t >= d ? s[t - d] : 0u; __syncthreads(); s[t] += y; __syncthreads(); }
+    if ((uint32_t)t < ntiles) tile_sum[t] = s[t] - v;
+    if (t == 1023) plan->total = s[1023];
+}
+// one wavefront per chunk writes { cbytes, block or chunk }; the first chunk of a block also writes the block's bstarts entry
+__global__ __launch_bounds__(256) void k_cbe_pack(const CbChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records, const uint8_t *__restrict__ filtered,
+                                                  const uint32_t *__restrict__ tile_off, uint32_t nchunks, uint32_t nsplit, uint32_t data0, uint8_t *__restrict__ frame) {
+    __shared__ uint32_t s[256];
+    const uint32_t t0 = blockIdx.x * 1024u;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // offsets of this tile's 1024 chunks: thread t owns chunks 4 t .. 4 t + 3
+    uint32_t mine[4], sum = 0;
+    for (uint32_t k = 0; k < 4u; k++) { const uint32_t c = t0 + 4u * t + k; mine[k] = c < nchunks ? cb_stream_bytes(desc[c]) : 0u; sum += mine[k]; }
+    s[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) { const uint32_t y = t >= d ? s[t - d] : 0u; __syncthreads(); s[t] += y; __syncthreads(); }
+    __shared__ uint32_t s_off[1024];
+    uint32_t o = data0 + tile_off[blockIdx.x] + s[t] - sum;
+    for (uint32_t k = 0; k < 4u; k++) { s_off[4u * t + k] = o; o += mine[k]; }
+    __syncthreads();
+    for (uint32_t k = w; k < 1024u; k += 4u) {                           // 4 wavefronts, a chunk each
+        const uint32_t c = t0 + k;
+        if (c >= nchunks) break;
+        const CbChunkDesc d = desc[c];
+        const uint32_t at = s_off[k];
+        const bool stored = d.enc_len >= HB_CHUNK;
+        const uint32_t cb = stored ? HB_CHUNK : d.enc_len;
+        if (lane < 4) frame[at + lane] = (uint8_t)(cb >> (8 * lane));
+        if (lane == 0 && c % nsplit == 0u) { const uint32_t b = c / nsplit; for (int q = 0; q < 4; q++) frame[16u + 4u * b + q] = (uint8_t)(at >> (8 * q)); }
+        wave_copy_g2g(frame + at + 4u, stored ? filtered + (size_t)c * HB_CHUNK : records + (size_t)c * HB_RSTRIDE, cb, lane);
+    }
+}
+// header, the last (shorter) block as one stored stream, the result
+__global__ __launch_bounds__(64) void k_cbe_finish(const CbEncPlan *plan, const uint8_t *__restrict__ filtered, uint32_t nbytes, uint32_t blocksize, uint32_t ts, uint32_t flags,
+                                                   uint32_t nfull_blocks, uint32_t data0, uint8_t *__restrict__ frame, uint64_t cap, hb_result *result) {
+    const int lane = threadIdx.x;
+    const uint32_t leftover = nbytes - nfull_blocks * blocksize;
+    const uint32_t at = data0 + plan->total;
+    const uint64_t cbytes = (uint64_t)at + (leftover ? 4u + leftover : 0u);
+    if (cbytes > cap || cbytes > 0xFFFFFFFFull) { if (lane == 0) { result->status = HB_ERR_SHORT_BUFFER; result->bytes = 0; result->total_bytes = 0; result->flags = 0; result->reserved = 0; } return; }
+    if (leftover) {
+        if (lane < 4) { frame[at + lane] = (uint8_t)(leftover >> (8 * lane)); frame[16u + 4u * nfull_blocks + lane] = (uint8_t)(at >> (8 * lane)); }
+        wave_copy_g2g(frame + at + 4u, filtered + (size_t)nfull_blocks * blocksize, leftover, lane);
+    }
+    if (lane == 0) {
+        frame[0] = 2; frame[1] = 1; frame[2] = (uint8_t)flags; frame[3] = (uint8_t)ts;                  // BLOSC_VERSION_FORMAT, LZ4 version format
+        for (int q = 0; q < 4; q++) { frame[4 + q] = (uint8_t)(nbytes >> (8 * q)); frame[8 + q] = (uint8_t)(blocksize >> (8 * q)); frame[12 + q] = (uint8_t)((uint32_t)cbytes >> (8 * q)); }
+        result->status = HB_OK; result->bytes = cbytes; result->total_bytes = cbytes; result->flags = 0; result->reserved = 0;
+    }
+}
+
+// inputs below one chunk: a memcpyed frame (what c-blosc itself writes for buffers it cannot shrink)
+__global__ void k_cbe_memcpy_header(uint8_t *frame, uint32_t nbytes, uint32_t ts, uint32_t flags, hb_result *result) {
+    const uint32_t cbytes = 16u + nbytes;
+    uint32_t bs = nbytes - nbytes % ts; if (bs == 0u) bs = nbytes ? 1u : 0u;
+    frame[0] = 2; frame[1] = 1; frame[2] = (uint8_t)flags; frame[3] = (uint8_t)ts;
+    for (int q = 0; q < 4; q++) { frame[4 + q] = (uint8_t)(nbytes >> (8 * q)); frame[8 + q] = (uint8_t)(bs >> (8 * q)); frame[12 + q] = (uint8_t)(cbytes >> (8 * q)); }
+    result->status = HB_OK; result->bytes = cbytes; result->total_bytes = cbytes; result->flags = 0; result->reserved = 0;
+}
+
+void hb_launch_match_selfcontained(const uint8_t *src, size_t n, void *desc, uint8_t *records, uint32_t nchunks, int accel, hipStream_t s);   // hb_lz4_enc.hip
+
+struct CbEncLayout { size_t plan, tiles, desc, records, filtered, total; uint32_t blocksize, nsplit, nblocks, nfull, nchunks, ntiles; };
+static CbEncLayout cbe_layout(size_t n, int shuffle, int typesize) {
+    CbEncLayout L;
+    const bool filt = (shuffle == 1 && typesize > 1) || shuffle == 2;
+    L.nsplit = (filt && typesize <= 16) ? (uint32_t)typesize : 1u;
+    if (n < (size_t)HB_CHUNK * L.nsplit) L.nsplit = 1u;                   // (c-blosc refuses a blocksize above nbytes)
+    L.blocksize = HB_CHUNK * L.nsplit;
+    L.nblocks = (uint32_t)((n + L.blocksize - 1) / L.blocksize);
+    L.nfull = (uint32_t)(n / L.blocksize);
+    L.nchunks = L.nfull * L.nsplit;
+    L.ntiles = (L.nchunks + 1023u) / 1024u;
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += cb_align(b); return at; };
+    L.plan = take(sizeof(CbEncPlan));
+    L.tiles = take((size_t)(L.ntiles + 1) * 4);
+    L.desc = take((size_t)L.nchunks * sizeof(CbChunkDesc));
+    L.records = take((size_t)L.nchunks * HB_RSTRIDE + 256);
+    L.filtered = take(n + 64);
+    L.total = o;
+    return L;
+}
+
 extern "C" {
 
 // header fields of a C-Blosc-1 frame (host side); HB_OK or the error a malformed header gets
@@ -205,4 +358,59 @@ int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, s
     return HB_OK;
 }
 
+
+size_t hb_cblosc_bound(size_t n, int typesize) {
+    const size_t ts = typesize > 0 ? (size_t)typesize : 1;
+    return 16 + 4 * (n / HB_CHUNK + 2) + n + 4 * (n / HB_CHUNK + ts + 2) + 64;
+}
+size_t hb_cblosc_compress_workspace(size_t n, int shuffle, int typesize) { return cbe_layout(n, shuffle, typesize > 0 ? typesize : 1).total; }
+
+// shuffle: 0 none, 1 byte shuffle, 2 bit shuffle (c-blosc's BLOSC_NOSHUFFLE / BLOSC_SHUFFLE / BLOSC_BITSHUFFLE).  Asynchronous on `stream`.
+int hb_cblosc_compress_dev(const void *d_src, size_t n, void *d_frame, size_t cap, int shuffle, int typesize, void *d_work, size_t work_bytes,
+                           hb_result *d_result, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if ((!d_src && n) || !d_frame || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if (typesize < 1 || typesize > 255 || shuffle < 0 || shuffle > 2) return HB_ERR_BAD_ARG;
+    if (n > 0x7FFFFFFFull - 64u * 1024u * 1024u) return HB_ERR_DATA_TOO_LARGE;           // (c-blosc: BLOSC_MAX_BUFFERSIZE = INT_MAX - 16)
+    if (cap < hb_cblosc_bound(n, typesize)) return HB_ERR_SHORT_BUFFER;
+    const CbEncLayout L = cbe_layout(n, shuffle, typesize);
+    if (work_bytes < L.total) return HB_ERR_SHORT_BUFFER;
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *w = (uint8_t *)d_work;
+    CbEncPlan *plan = (CbEncPlan *)(w + L.plan);
+    uint32_t *tiles = (uint32_t *)(w + L.tiles);
+    CbChunkDesc *desc = (CbChunkDesc *)(w + L.desc);
+    uint8_t *records = w + L.records, *filtered = w + L.filtered;
+    const bool unshuf = shuffle == 1 && typesize > 1, bits = shuffle == 2;
+    const uint32_t flags = (unshuf ? CB_FLAG_SHUFFLE : 0u) | (bits ? CB_FLAG_BITSHUFFLE : 0u) | (L.nsplit == 1u ? CB_FLAG_DONTSPLIT : 0u) | (1u << 5);
+    if (n < HB_CHUNK) {
+        if (n) HB_HIP_TRY(hipMemcpyAsync((uint8_t *)d_frame + 16, d_src, n, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_cbe_memcpy_header, dim3(1), dim3(1), 0, s, (uint8_t *)d_frame, (uint32_t)n, (uint32_t)typesize, flags | CB_FLAG_MEMCPY | CB_FLAG_DONTSPLIT, d_result);
+        HB_HIP_TRY(hipGetLastError());
+        return HB_OK;
+    }
+    const uint8_t *fsrc = (const uint8_t *)d_src;
+    hb_prof_begin("k_cb_filter", s);
+    if (n && (unshuf || bits)) {
+        if (unshuf) hipLaunchKernelGGL(k_cb_shuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
+        else hipLaunchKernelGGL(k_cb_bitshuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
+        fsrc = filtered;
+    }
+    hb_prof_end(s);
+    HB_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(CbEncPlan), s));
+    if (L.nchunks) {
+        hb_prof_begin("k_match", s);
+        hb_launch_match_selfcontained(fsrc, (size_t)L.nchunks * HB_CHUNK, desc, records, L.nchunks, 64, s);
+        hb_prof_end(s);
+        hb_prof_begin("k_cbe_pack", s);
+        hipLaunchKernelGGL(k_cbe_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tiles);
+        hipLaunchKernelGGL(k_cbe_scan, dim3(1), dim3(1024), 0, s, tiles, L.ntiles, plan);
+        hipLaunchKernelGGL(k_cbe_pack, dim3(L.ntiles), dim3(256), 0, s, desc, records, fsrc, tiles, L.nchunks, L.nsplit, 16u + 4u * L.nblocks, (uint8_t *)d_frame);
+        hb_prof_end(s);
+    }
+    hipLaunchKernelGGL(k_cbe_finish, dim3(1), dim3(64), 0, s, plan, fsrc, (uint32_t)n, L.blocksize, (uint32_t)typesize, flags, L.nfull, 16u + 4u * L.nblocks, (uint8_t *)d_frame,
+                       (uint64_t)cap, d_result);
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}
 }  // extern "C"

@@ -149,10 +149,12 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 //       complete, self-contained element stream (a Snappy block is a plain concatenation of elements: nothing to stitch).
 // accel: bytes by which a step without any hit widens the stride (LZ4-style skip acceleration; Options.Level as a speed knob:
 //       128 for levels 1-3, 64 for 4-6 (the default level 5), 0 for 7-9 and for every LZ4HC level).
-template <int WAYS, bool SNAPPY>
+template <int WAYS, int MODE>
 __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_t sh, const int len,
                                             uint8_t *s_out /* SOUT + 16 */, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */, uint32_t *s_st /* 8 words */,
                                             ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const bool keep_long, const int accel, const int lane) {
+    constexpr bool SNAPPY = MODE == 1;        // MODE 0: LZ4 sequences for k_stitch, 1: Snappy elements, 2: a self-contained LZ4 block per chunk
+    constexpr bool SELF = MODE == 2;
     {
         {
             u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
@@ -220,7 +222,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t end = q_mp + q_ml;
             const uint32_t prev = wave_shr1(end, batch_anchor);
             const uint32_t lit = q_mp - prev, mcode = q_ml - 4u;
-            const bool first = (nseq == 0) && lane == 0;  // sequence 0 of the chunk: token comes from k_stitch
+            const bool first = !SELF && (nseq == 0) && lane == 0;  // sequence 0 of the chunk: token comes from k_stitch (not when the chunk is a block of its own)
             const uint32_t nbl = first ? 0u : lz4_ext_bytes(lit), nbm = lz4_ext_bytes(mcode);
             const uint32_t size = lane < take ? ((first ? 0u : 1u) + nbl + lit + 2u + nbm) : 0u;
             const uint32_t incl = wave_incl_scan_dpp(size);
@@ -611,6 +613,29 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             wave_sync();
             return;
         }
+        if constexpr (SELF) {
+            // the chunk is an LZ4 block of its own (a stream of a C-Blosc-1 frame, hb_cblosc.hip): the rest of the chunk is the final,
+            // literal-only sequence (never empty: the last 5 bytes of a chunk are literals, a chunk below 13 bytes has no match)
+            const uint32_t tl = (uint32_t)(len - anchor);
+            const uint32_t nb = lz4_ext_bytes(tl);
+            if (lane == 0) {
+                uint32_t q = opend;
+                s_out[q++] = (uint8_t)((tl < 15u ? tl : 15u) << 4);
+                if (nb) { for (uint32_t k = 0; k + 1 < nb; k++) s_out[q++] = 255; s_out[q++] = (uint8_t)((tl - 15u) - 255u * (nb - 1)); }
+            }
+            opend += 1u + nb;
+            wave_sync();
+            stream_literals((uint32_t)anchor, tl);
+            const uint32_t total = rec_done + opend;
+            drain(true);
+            if (lane == 0) {
+                ChunkDesc d;
+                d.lead = 0u; d.enc_len = total; d.last_end = (uint32_t)len; d.mcode0 = 0u;
+                *dsc = d;
+            }
+            wave_sync();
+            return;
+        }
         const uint32_t enc = rec_done + opend;             // record bytes without the trailing literals
         if (with_trailing) {
             if (nseq == 0 && sh == 0) {            // no match at all: the record is the image itself
@@ -635,7 +660,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 // bits4 != 0: src is the UN-filtered input and go-blosc's bitshuffle for typesize 4 (an in-place transform of every
 // 32-byte window, shuffle.go:184-200) is applied to the chunk image in LDS -- filter fused, no filtered buffer in
 // HBM; the caller guarantees n % 32 == 0 and a 16-byte aligned src.
-template <int WAYS, bool SNAPPY>
+template <int WAYS, int MODE>
 __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
                                               uint32_t nchunks, int bits4, int keep_long, int accel) {
@@ -665,7 +690,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                 ((u32x4 *)s_data)[2 * w + 1] = ob;
             }
         }
-        match_chunk<WAYS, SNAPPY>(s_data, sh, len, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, keep_long != 0, accel, lane);
+        match_chunk<WAYS, MODE>(s_data, sh, len, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, bits4 != 0, keep_long != 0, accel, lane);
     }
 }
 
@@ -675,7 +700,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 // elements, and builds the chunk image in LDS.  The TS waves of a block read the same bytes; they are given
 // workgroup ids that are equal mod 8 (same XCD under round-robin placement: they share the L2 lines -- speed
 // only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
-template <int TS, int WAYS, bool SNAPPY>
+template <int TS, int WAYS, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 6 : 4))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
                                                     uint8_t *__restrict__ records, uint32_t nblk, uint32_t plane_mask, int accel) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
@@ -743,7 +768,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
             }
         }
         const uint32_t ck = j * nblk + b;
-        match_chunk<WAYS, SNAPPY>(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, accel, lane);
+        match_chunk<WAYS, MODE>(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, accel, lane);
     }
 }
 
@@ -1126,6 +1151,12 @@ static void launch_match(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, u
     else if (ways == 1) HB_LAUNCH_MATCH(1, false);
     else if (ways == 2) HB_LAUNCH_MATCH(2, false);
     else HB_LAUNCH_MATCH(4, false);
+}
+
+// every HB_CHUNK bytes of src become an LZ4 block of their own (hb_cblosc.hip): records + descriptors only, nothing is stitched
+void hb_launch_match_selfcontained(const uint8_t *src, size_t n, void *desc, uint8_t *records, uint32_t nchunks, int accel, hipStream_t s) {
+    const unsigned grid = nchunks < 256u * 256u ? nchunks : 256u * 256u;
+    hipLaunchKernelGGL((k_match<1, 2>), dim3(grid), dim3(64), 0, s, src, (uint64_t)n, (ChunkDesc *)desc, records, nchunks, 0, 0, accel);
 }
 
 int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {

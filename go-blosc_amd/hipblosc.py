@@ -88,7 +88,7 @@ EXPORTS = [
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace", "hb_decompress_frame_workspace_foreign", "hb_lz4_decompress_workspace_foreign",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
-    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_cblosc_parse_header", "hb_cblosc_decompress", "hb_cblosc_decompress_workspace", "hb_cblosc_decompress_dev",
+    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_cblosc_parse_header", "hb_cblosc_decompress", "hb_cblosc_compress", "hb_cblosc_bound", "hb_cblosc_compress_workspace", "hb_cblosc_compress_dev", "hb_cblosc_decompress_workspace", "hb_cblosc_decompress_dev",
     "hb_queue_create", "hb_queue_create_ex", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
 
@@ -145,7 +145,9 @@ def lib():
             "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
             "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),
             "hb_debug_decode_fusion": (None, [i32]), "hb_debug_plane_mask": (None, [u32]),
-            "hb_cblosc_parse_header": (i32, [vp, sz, vp]), "hb_cblosc_decompress": (i64, [vp, sz, vp, sz, i32]),
+            "hb_cblosc_parse_header": (i32, [vp, sz, vp]), "hb_cblosc_compress": (i64, [vp, sz, vp, sz, i32, i32, i32]),
+            "hb_cblosc_bound": (sz, [sz, i32]), "hb_cblosc_compress_workspace": (sz, [sz, i32, i32]),
+            "hb_cblosc_compress_dev": (i32, [vp, sz, vp, sz, i32, i32, vp, sz, vp, vp]), "hb_cblosc_decompress": (i64, [vp, sz, vp, sz, i32]),
             "hb_cblosc_decompress_workspace": (sz, [sz, sz, sz]), "hb_cblosc_decompress_dev": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, vp]),
             "hb_queue_create": (vp, [i32, i32, sz]), "hb_queue_create_ex": (vp, [i32, i32, sz, ctypes.c_uint]), "hb_queue_destroy": (None, [vp]),
             "hb_queue_compress": (i64, [vp, vp, sz, vp, sz, i32, i32, i32, i32, u32]),
@@ -461,4 +463,13 @@ def CBloscDecompress(frame):
     h = CBloscParseHeader(frame)
     out = ctypes.create_string_buffer(max(h.nbytes, 1))
     rc = _check(lib().hb_cblosc_decompress(p, n, ctypes.cast(out, ctypes.c_void_p), h.nbytes, device))
+    return out.raw[:rc]
+
+
+def CBloscCompress(data, shuffle=1, typesize=4):
+    """A frame blosc_decompress() of c-blosc 1.x reads (include/hipblosc.h hb_cblosc_compress); shuffle 0 / 1 / 2 = none / byte / bit."""
+    p, n, keep = _buf(data)
+    cap = lib().hb_cblosc_bound(n, typesize)
+    out = ctypes.create_string_buffer(cap)
+    rc = _check(lib().hb_cblosc_compress(p, n, ctypes.cast(out, ctypes.c_void_p), cap, shuffle, typesize, device))
     return out.raw[:rc]

@@ -221,8 +221,8 @@ int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst,
 int64_t hb_queue_wait(hb_queue *q, int64_t ticket);
 
 /* ---- frames in the C-Blosc-1 wire format (c-blosc 1.x: bstarts table, blocks split into `typesize` streams, the
- *      filter per block) -- what go-blosc's README.md:20 claims to be compatible with and blosc.go does not implement.  Decoding
- *      only, codec formats LZ4 / LZ4HC and memcpyed frames; byte shuffle, bit shuffle or none, any typesize.  Not a seam of the
+ *      filter per block) -- what go-blosc's README.md:20 claims to be compatible with and blosc.go does not implement.  Codec
+ *      formats LZ4 / LZ4HC and memcpyed frames; byte shuffle, bit shuffle or none, any typesize.  Not a seam of the
  *      reference (it has none for this): an extension next to hb_decompress_frame. ---- */
 typedef struct hb_cblosc_header {
     uint8_t  version, versionlz, flags, typesize;   /* flags: 0x01 shuffle, 0x02 memcpyed, 0x04 bitshuffle, 0x10 not split */
@@ -236,6 +236,15 @@ int     hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_fram
 /* host pointers: returns the decoded bytes (== nbytes of the header) or HB_ERR_*: HB_ERR_INVALID_CODEC for the codec formats
  * that are not LZ4, HB_ERR_DECOMPRESSION_FAILED for anything blosc_decompress() answers with a negative number */
 int64_t hb_cblosc_decompress(const void *frame, size_t n, void *dst, size_t cap, int device);
+/* writing the format: a frame that blosc_decompress() of c-blosc 1.x (python-blosc, numcodecs ...) reads.  shuffle: 0 none, 1 byte
+ * shuffle, 2 bit shuffle (BLOSC_NOSHUFFLE / BLOSC_SHUFFLE / BLOSC_BITSHUFFLE); LZ4 streams; block size 4096 x typesize (split) or
+ * 4096 (not split), so that every stream is one chunk of this library's encoder; n below 2 GiB (c-blosc's limit).  Returns the
+ * frame's bytes (its cbytes field). */
+size_t  hb_cblosc_bound(size_t n, int typesize);
+size_t  hb_cblosc_compress_workspace(size_t n, int shuffle, int typesize);
+int     hb_cblosc_compress_dev(const void *d_src, size_t n, void *d_frame, size_t cap, int shuffle, int typesize,
+                               void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+int64_t hb_cblosc_compress(const void *src, size_t n, void *dst, size_t cap, int shuffle, int typesize, int device);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,28 @@ def test_what_must_be_refused(hb, O, cb):
         hb.CBloscDecompress(bytes(g))
 
 
+def test_frames_written_here_are_read_by_the_library(hb, O, cb):
+    # the other direction: hb_cblosc_compress writes, blosc_decompress_ctx of c-blosc 1.21 reads (and the device decoder too)
+    sets = _sets(O)
+    sets["tiny"] = np.arange(13, dtype=np.uint8)
+    sets["one_chunk_and_a_bit"] = O.synth(O.D_F32, 1024 + 3)
+    for name, x in sets.items():
+        xb = x.tobytes()
+        for ts in (1, 2, 3, 4, 8, 16, 17):
+            for shuffle in (0, 1, 2):
+                f = hb.CBloscCompress(xb, shuffle, ts)
+                h = hb.CBloscParseHeader(f)
+                assert (h.version, h.nbytes, h.cbytes, h.codec_format, h.typesize) == (2, len(xb), len(f), 1, ts), (name, ts, shuffle)
+                r, out = cb.decompress(f, len(xb))
+                assert r == len(xb) and out == xb, (name, ts, shuffle, r)
+                assert hb.CBloscDecompress(f) == xb, (name, ts, shuffle)
+    # ratio: the chunk-local encoder's, a few bytes per 4 KiB stream on top
+    x = O.synth(O.D_F32, (8 << 20) // 4)
+    f = hb.CBloscCompress(x.tobytes(), 1, 4)
+    g = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.Shuffle1, 4, opts=0)
+    assert len(f) < len(g) * 1.02, (len(f), len(g))
+
+
 def test_a_large_frame(hb, O, cb):
     import time
     x = O.synth(O.D_F32, (256 << 20) // 4)
