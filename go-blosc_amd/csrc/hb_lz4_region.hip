@@ -1,30 +1,31 @@
-// hb_lz4_region.hip — rebuilds the restart index of an LZ4 block that comes WITHOUT one (a frame written without
-// HB_OPT_INDEX_TRAILER -- the drop-in default, since the reference's frames end at NBytesComp; blosc.go:369-371), so that it decodes
-// chunk-parallel instead of on one wavefront.  Input contract: that of lz4.UncompressBlock (codec.go:77-84), nothing more.
+// hb_lz4_region.hip — token discovery for an LZ4 block that comes WITHOUT a restart index (a frame written without
+// HB_OPT_INDEX_TRAILER -- the drop-in default, since the reference's frames end at NBytesComp; blosc.go:369-371 -- or a frame the
+// reference itself wrote), so that it decodes in parallel instead of on one wavefront.  Input contract: that of
+// lz4.UncompressBlock (codec.go:77-84), nothing more.
 //
 // Two things make such a block serial: (1) nothing says where its sequences start -- token k+1 begins where token k ends;
 // (2) a match may copy from up to 65535 bytes back, i.e. from output that some other part of the stream produces.
 // Both are resolved by GUESSING in parallel and then VERIFYING exactly; wrong guesses are repaired by iteration, and anything
 // that does not check out leaves the block to the single-wavefront decoder (k_dec_serial), so the result never depends on luck.
 //
-//   (1) Sequence boundaries.  The stream is cut into R regions at fixed byte positions b_r.  k_rg_parse: one wavefront per
-//       region parses (window-parallel token parser of hb_dec_common.h, no copies) from b_r AS IF a token started there, to
-//       the first token at or after b_{r+1}; it keeps that exit, the output length, and a trace {position, output so far} of
-//       its first 256 tokens.  A parse started at a wrong byte is garbage, but LZ4 parses synchronise: after a few tokens the
-//       garbage parse usually falls onto a real token boundary and stays on the real chain.  k_rg_fix then walks the chain of
-//       beliefs "my first token = my predecessor's exit": region 0 is exact (a block starts with a token); a region whose
-//       belief changed re-parses from the new entry ONE token at a time until it lands on a position of its trace (the parses
-//       have merged: exit unchanged, output length corrected by the difference) -- or is re-parsed in full.  A few rounds, then
-//       k_rg_scan checks the whole chain (entry[r] == exit[r-1] for every r, last exit == end of block): a chain that passes is
-//       the true token chain, however it was found.  The prefix sum of the output lengths gives every region its place.
-//   (2) Match sources.  An arbitrary block cannot be decoded in pieces: in a stream with few literals and a 64 KiB window (what a
-//       CPU encoder writes on compressible data) every byte hangs on a long chain of earlier matches, and a decoder that starts
-//       somewhere in the middle with a wrong history never recovers (measured with a round-based re-decode of regions: on the
-//       reference-shaped D-f32 stream correctness advanced about two regions per round -- DESIGN.md).  What CAN be decoded in pieces
-//       is a block whose matches never leave their 4 KiB chunk of output: every block THIS library writes, with or without the
-//       index trailer.  So the second half rebuilds that trailer: k_rg_index walks the verified chain once more, now with output
-//       positions, and writes the HBIX entry of every 4 KiB unit -- or gives up at the first unit boundary that falls inside a
-//       match.  The rebuilt index then goes through k_dec_plan / k_dec_indexed like a stored one, which trust neither.
+//   (1) Sequence boundaries (this file).  The stream is cut into <= 8192 regions at fixed byte positions b_r.  k_rg_parse: one
+//       wavefront per region parses (window-parallel token parser, hb_lz4_region.h, no copies) to the first token at or after
+//       b_{r+1}, starting at a token it spotted by its long length extension (a run of FF bytes) or else at b_r AS IF a token
+//       started there; it keeps that exit, the output length, and a record {position, output so far} of its first 128 tokens and
+//       of the first token in each of 128 slices of the region.  A parse started at a wrong byte is garbage, but LZ4 parses
+//       synchronise: it usually falls onto a real token and stays on the real chain.  Beliefs "my first token = the furthest
+//       position any region in front of me reaches" are then iterated (k_rg_pmax + k_rg_fix chip-wide, k_rg_settle with the
+//       regions' state in LDS): a region whose belief changed walks a few tokens looking for a position of its record (the
+//       parses have merged: exit unchanged, output length corrected by the difference) or is re-parsed in merge mode; what is
+//       still moving after the chip-wide rounds (a stretch whose parses never synchronise) is finished by the last k_rg_settle
+//       launch itself.  k_rg_scan checks the whole chain (entry[r] == exit[r-1] for every r, last exit == end of block): a
+//       chain that passes is the true token chain, however it was found; the prefix sum of the output lengths gives every
+//       region its place.
+//   (2) Match sources.  A block whose matches never leave their 4 KiB chunk of output -- every block THIS library writes -- gets
+//       its restart index rebuilt: k_rg_index walks the verified chain with output positions and writes the HBIX entry of every
+//       4 KiB unit, or gives up at the first unit boundary that falls inside a match; the rebuilt index goes through k_dec_plan /
+//       k_dec_indexed like a stored one, which trust neither.  Any other block (the reference's: one block, 64 KiB window) is
+//       decoded symbolically from the same chain: hb_lz4_sym.hip.
 //
 // Everything malformed (offset 0, offset before the block, lengths running off the stream, output beyond cap) only raises
 // plan->fail; k_dec_serial then decodes the block and reports what lz4.UncompressBlock would report.

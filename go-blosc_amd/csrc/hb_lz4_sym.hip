@@ -8,15 +8,20 @@
 // ever named).  Copies copy references like values, so after one pass every output byte is either a value or a reference into the
 // 65535 bytes in front of its region -- chains of matches inside the region are flattened by the decode itself.
 //
-//   pass A  k_sy_decode    one wavefront per region: tokens 64 at a time, one per lane (window-parallel parser), literals and matches
-//                          copied lane-parallel in dependency rounds straight in HBM; values go to the output buffer, references to a
-//                          u16 side array (0 = "is a value").
-//   pass B  the 65535 bytes in front of a region are the tail of its predecessors, themselves symbolic: the tail of region r as a
+//   units   k_sy_units / k_sy_compact: one unit per region; a region with more than 1 MiB of output is cut into 8 at tokens the
+//           discovery has on record (one wavefront copying 14 MiB of KiB-long matches is what everybody else would wait for).
+//   pass A  k_sy_decode    one wavefront per unit (the unit decoder of hb_sym_decode.h): tokens 64 at a time, one per lane; the last
+//                          4 KiB of output live in LDS, matches into it run LDS to LDS in dependency rounds, older sources are
+//                          fetched from HBM all lanes at once; values go to the output buffer, references to a u16 side array
+//                          (0 = "is a value").  Literal runs / matches of 256 KiB and more are posted and copied by the whole chip
+//                          (k_sy_big) between two launches.
+//   pass B  the 65535 bytes in front of a unit are the tail of its predecessors, themselves symbolic: the tail of unit r as a
 //           function of the tail in front of it is a MAP of 65535 entries {value | reference}, maps compose associatively, so the
-//           tails are resolved by a scan over the regions: k_sy_compose (per group of regions: the composed map, sequential inside
+//           tails are resolved by a scan over the units: k_sy_compose (per group of units: the composed map, sequential inside
 //           the group, groups in parallel), k_sy_chain (one workgroup: the resolved tail in front of every group, one map per step,
-//           the tail in LDS), k_sy_resolve (per group again: every region's bytes resolved against the now known tail in front of
-//           it -- 64 KiB of LDS, one byte gather per reference -- and the tail rolled forward).
+//           the tail in LDS), k_sy_tails (per group again: every unit's last 64 KiB resolved against a 64 KiB ring in LDS that
+//           rolls forward), k_sy_resolve (all the other bytes, in pieces over the whole chip: the 64 KiB in front of a unit are
+//           final by then and are read back into LDS; one byte gather per reference).
 //
 // Whatever is wrong with the stream (offset 0, offset before the start of the block) only raises SyPlan.fail: the single wavefront
 // then decodes and reports what lz4.UncompressBlock reports.  A block that passes is decoded to exactly the bytes the serial
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
 }
 
 // the copies pass A posted, with the whole chip: 16 KiB per workgroup and step
-__global__ __launch_bounds__(256) void k_sy_big(const uint8_t *__restrict__ src, SyPlan *sy, const SyBig *__restrict__ big, uint8_t *D, uint16_t *S, int reset) {
+__global__ __launch_bounds__(256) void k_sy_big(const uint8_t *__restrict__ src, SyPlan *sy, const SyBig *__restrict__ big, uint8_t *D, uint16_t *S) {
     if (!sy->go || sy->fail) return;
     const uint32_t nb = sy->nbig;
     const int t = threadIdx.x;
@@ -194,7 +199,6 @@ __global__ __launch_bounds__(256) void k_sy_big(const uint8_t *__restrict__ src,
             }
         }
     }
-    (void)reset;
 }
 // between two launches of pass A
 __global__ void k_sy_big_reset(SyPlan *sy) { sy->nbig = 0; }
@@ -453,7 +457,7 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
         hb_prof_end(s);
         if (!last) {
             hb_prof_begin("k_sy_big", s);
-            hipLaunchKernelGGL(k_sy_big, dim3(1024), dim3(256), 0, s, a.src, sy, big, dst, S, 0);
+            hipLaunchKernelGGL(k_sy_big, dim3(1024), dim3(256), 0, s, a.src, sy, big, dst, S);
             hipLaunchKernelGGL(k_sy_big_reset, dim3(1), dim3(1), 0, s, sy);
             hb_prof_end(s);
         }
