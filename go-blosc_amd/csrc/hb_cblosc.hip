@@ -186,11 +186,13 @@ struct CbChunkDesc { uint32_t lead, enc_len, last_end, mcode0; };       // = Chu
 // bytes of stream c in the frame: 4 + the block, or 4 + the chunk itself when the block is no smaller
 __device__ __forceinline__ uint32_t cb_stream_bytes(const CbChunkDesc &d) { return 4u + (d.enc_len < HB_CHUNK ? d.enc_len : HB_CHUNK); }
 // exclusive prefix sum of the stream sizes, 1024 chunks per tile: tile sums, one workgroup over the tiles, offsets
-__global__ __launch_bounds__(256) void k_cbe_tiles(const CbChunkDesc *__restrict__ desc, uint32_t nchunks, uint32_t *__restrict__ tile_sum) {
+// (fused_nblk != 0: the descriptors / records come from the fused shuffle + match kernel, stream (block b, plane j) at index j * nblk + b)
+__device__ __forceinline__ uint32_t cb_desc_index(uint32_t c, uint32_t nsplit, uint32_t fused_nblk) { return fused_nblk ? (c % nsplit) * fused_nblk + c / nsplit : c; }
+__global__ __launch_bounds__(256) void k_cbe_tiles(const CbChunkDesc *__restrict__ desc, uint32_t nchunks, uint32_t nsplit, uint32_t fused_nblk, uint32_t *__restrict__ tile_sum) {
     __shared__ uint32_t s[256];
     const uint32_t t0 = blockIdx.x * 1024u;
     uint32_t sum = 0;
-    for (uint32_t k = 0; k < 4u; k++) { const uint32_t c = t0 + k * 256u + threadIdx.x; if (c < nchunks) sum += cb_stream_bytes(desc[c]); }
+    for (uint32_t k = 0; k < 4u; k++) { const uint32_t c = t0 + k * 256u + threadIdx.x; if (c < nchunks) sum += cb_stream_bytes(desc[cb_desc_index(c, nsplit, fused_nblk)]); }
     s[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d]; __syncthreads(); }
@@ -207,32 +209,50 @@ __global__ __launch_bounds__(1024) void k_cbe_scan(uint32_t *tile_sum, uint32_t 
     if ((uint32_t)t < ntiles) tile_sum[t] = s[t] - v;
     if (t == 1023) plan->total = s[1023];
 }
-// one wavefront per chunk writes { cbytes, block or chunk }; the first chunk of a block also writes the block's bstarts entry
-__global__ __launch_bounds__(256) void k_cbe_pack(const CbChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records, const uint8_t *__restrict__ filtered,
-                                                  const uint32_t *__restrict__ tile_off, uint32_t nchunks, uint32_t nsplit, uint32_t data0, uint8_t *__restrict__ frame) {
-    __shared__ uint32_t s[256];
+// one wavefront per chunk writes { cbytes, block or chunk }; the first chunk of a block also writes the block's bstarts entry.
+// 1024 chunks per workgroup of 16 wavefronts: latency-bound small copies, so as many of them in flight as the chip takes.
+__global__ __launch_bounds__(1024) void k_cbe_pack(const CbChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records, const uint8_t *__restrict__ filtered,
+                                                   const uint32_t *__restrict__ tile_off, uint32_t nchunks, uint32_t nsplit, uint32_t fused_nblk, uint32_t data0, uint8_t *__restrict__ frame) {
+    __shared__ uint32_t s[1024];
+    __shared__ uint32_t s_off[1024];
     const uint32_t t0 = blockIdx.x * 1024u;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    // offsets of this tile's 1024 chunks: thread t owns chunks 4 t .. 4 t + 3
-    uint32_t mine[4], sum = 0;
-    for (uint32_t k = 0; k < 4u; k++) { const uint32_t c = t0 + 4u * t + k; mine[k] = c < nchunks ? cb_stream_bytes(desc[c]) : 0u; sum += mine[k]; }
-    s[t] = sum;
+    const uint32_t c_mine = t0 + (uint32_t)t;
+    const uint32_t mine = c_mine < nchunks ? cb_stream_bytes(desc[cb_desc_index(c_mine, nsplit, fused_nblk)]) : 0u;
+    s[t] = mine;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) { const uint32_t y = t >= d ? s[t - d] : 0u; __syncthreads(); s[t] += y; __syncthreads(); }
-    __shared__ uint32_t s_off[1024];
-    uint32_t o = data0 + tile_off[blockIdx.x] + s[t] - sum;
-    for (uint32_t k = 0; k < 4u; k++) { s_off[4u * t + k] = o; o += mine[k]; }
+    for (int d = 1; d < 1024; d <<= 1) { const uint32_t y = t >= d ? s[t - d] : 0u; __syncthreads(); s[t] += y; __syncthreads(); }
+    s_off[t] = data0 + tile_off[blockIdx.x] + s[t] - mine;
     __syncthreads();
-    for (uint32_t k = w; k < 1024u; k += 4u) {                           // 4 wavefronts, a chunk each
+    for (uint32_t k = w; k < 1024u; k += 16u) {
         const uint32_t c = t0 + k;
         if (c >= nchunks) break;
-        const CbChunkDesc d = desc[c];
+        const uint32_t ci = cb_desc_index(c, nsplit, fused_nblk);
+        const CbChunkDesc d = desc[ci];
         const uint32_t at = s_off[k];
         const bool stored = d.enc_len >= HB_CHUNK;
         const uint32_t cb = stored ? HB_CHUNK : d.enc_len;
         if (lane < 4) frame[at + lane] = (uint8_t)(cb >> (8 * lane));
         if (lane == 0 && c % nsplit == 0u) { const uint32_t b = c / nsplit; for (int q = 0; q < 4; q++) frame[16u + 4u * b + q] = (uint8_t)(at >> (8 * q)); }
-        wave_copy_g2g(frame + at + 4u, stored ? filtered + (size_t)c * HB_CHUNK : records + (size_t)c * HB_RSTRIDE, cb, lane);
+        if (stored && fused_nblk) {                                    // no filtered buffer: plane j of element block b, gathered from the input
+            const uint8_t *e = filtered + (size_t)(c / nsplit) * HB_CHUNK * nsplit;           // (16-byte aligned: the fused path asks for it)
+            const uint32_t j = c % nsplit, per = 16u / nsplit;                                // nsplit = typesize = 2 / 4 / 8: elements per 16 bytes
+            const uint32_t nv = HB_CHUNK * nsplit / 16u;                                       // 512 / 1024 / 2048 vectors: 8 / 16 / 32 per lane
+            for (uint32_t i0 = lane; i0 < nv; i0 += 64u * 8u) {                                // 8 loads in flight per lane
+                u32x4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = *(const u32x4 *)(e + 16u * (size_t)(i0 + 64u * q));
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t i = i0 + 64u * q;
+                    const uint32_t wv[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                    uint64_t o = 0;
+                    for (uint32_t kk = 0; kk < per; kk++) { const uint32_t byte = kk * nsplit + j; o |= (uint64_t)((wv[byte >> 2] >> (8u * (byte & 3u))) & 255u) << (8u * kk); }
+                    uint8_t *dp = frame + at + 4u + i * per;
+                    if (per == 8u) st8u(dp, o); else if (per == 4u) st4u(dp, (uint32_t)o); else { dp[0] = (uint8_t)o; dp[1] = (uint8_t)(o >> 8); }
+                }
+            }
+        } else wave_copy_g2g(frame + at + 4u, stored ? filtered + (size_t)c * HB_CHUNK : records + (size_t)ci * HB_RSTRIDE, cb, lane);
     }
 }
 // header, the last (shorter) block as one stored stream, the result
@@ -264,6 +284,7 @@ __global__ void k_cbe_memcpy_header(uint8_t *frame, uint32_t nbytes, uint32_t ts
 }
 
 void hb_launch_match_selfcontained(const uint8_t *src, size_t n, void *desc, uint8_t *records, uint32_t nchunks, int accel, hipStream_t s);   // hb_lz4_enc.hip
+bool hb_launch_match_fused_selfcontained(const uint8_t *src, int typesize, void *desc, uint8_t *records, uint32_t nblk, int accel, hipStream_t s);
 
 struct CbEncLayout { size_t plan, tiles, desc, records, filtered, total; uint32_t blocksize, nsplit, nblocks, nfull, nchunks, ntiles; };
 static CbEncLayout cbe_layout(size_t n, int shuffle, int typesize) {
@@ -390,25 +411,33 @@ int hb_cblosc_compress_dev(const void *d_src, size_t n, void *d_frame, size_t ca
         return HB_OK;
     }
     const uint8_t *fsrc = (const uint8_t *)d_src;
+    // byte shuffle with typesize 2 / 4 / 8 and split blocks: a C-Blosc block of 4096 elements IS the unit of the fused shuffle + match
+    // kernel (hb_lz4_enc.hip), only the order of the chunks differs -- no filtered buffer, except for the last, shorter block
+    const bool fuse = unshuf && L.nsplit == (uint32_t)typesize && (typesize == 2 || typesize == 4 || typesize == 8) && L.nfull != 0u && ((uintptr_t)d_src & 15u) == 0;
+    const uint32_t tail = (uint32_t)(n - (size_t)L.nfull * L.blocksize);
     hb_prof_begin("k_cb_filter", s);
-    if (n && (unshuf || bits)) {
+    if (fuse) {
+        if (tail) hipLaunchKernelGGL(k_cb_shuffle, dim3(64), dim3(256), 0, s, filtered + (size_t)L.nfull * L.blocksize, (const uint8_t *)d_src + (size_t)L.nfull * L.blocksize, tail, L.blocksize, (uint32_t)typesize);
+    } else if (unshuf || bits) {
         if (unshuf) hipLaunchKernelGGL(k_cb_shuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
         else hipLaunchKernelGGL(k_cb_bitshuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
         fsrc = filtered;
     }
     hb_prof_end(s);
     HB_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(CbEncPlan), s));
+    const uint32_t fused_nblk = fuse ? L.nfull : 0u;
     if (L.nchunks) {
         hb_prof_begin("k_match", s);
-        hb_launch_match_selfcontained(fsrc, (size_t)L.nchunks * HB_CHUNK, desc, records, L.nchunks, 64, s);
+        if (fuse) hb_launch_match_fused_selfcontained((const uint8_t *)d_src, typesize, desc, records, L.nfull, 64, s);
+        else hb_launch_match_selfcontained(fsrc, (size_t)L.nchunks * HB_CHUNK, desc, records, L.nchunks, 64, s);
         hb_prof_end(s);
         hb_prof_begin("k_cbe_pack", s);
-        hipLaunchKernelGGL(k_cbe_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tiles);
+        hipLaunchKernelGGL(k_cbe_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, L.nsplit, fused_nblk, tiles);
         hipLaunchKernelGGL(k_cbe_scan, dim3(1), dim3(1024), 0, s, tiles, L.ntiles, plan);
-        hipLaunchKernelGGL(k_cbe_pack, dim3(L.ntiles), dim3(256), 0, s, desc, records, fsrc, tiles, L.nchunks, L.nsplit, 16u + 4u * L.nblocks, (uint8_t *)d_frame);
+        hipLaunchKernelGGL(k_cbe_pack, dim3(L.ntiles), dim3(1024), 0, s, desc, records, fsrc, tiles, L.nchunks, L.nsplit, fused_nblk, 16u + 4u * L.nblocks, (uint8_t *)d_frame);
         hb_prof_end(s);
     }
-    hipLaunchKernelGGL(k_cbe_finish, dim3(1), dim3(64), 0, s, plan, fsrc, (uint32_t)n, L.blocksize, (uint32_t)typesize, flags, L.nfull, 16u + 4u * L.nblocks, (uint8_t *)d_frame,
+    hipLaunchKernelGGL(k_cbe_finish, dim3(1), dim3(64), 0, s, plan, fuse ? (const uint8_t *)filtered : fsrc, (uint32_t)n, L.blocksize, (uint32_t)typesize, flags, L.nfull, 16u + 4u * L.nblocks, (uint8_t *)d_frame,
                        (uint64_t)cap, d_result);
     HB_HIP_TRY(hipGetLastError());
     return HB_OK;

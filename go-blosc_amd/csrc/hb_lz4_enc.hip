@@ -1159,6 +1159,18 @@ void hb_launch_match_selfcontained(const uint8_t *src, size_t n, void *desc, uin
     hipLaunchKernelGGL((k_match<1, 2>), dim3(grid), dim3(64), 0, s, src, (uint64_t)n, (ChunkDesc *)desc, records, nchunks, 0, 0, accel);
 }
 
+// the same with the byte shuffle fused (typesize 2 / 4 / 8): chunk (plane j, element block b) lands at index j * nblk + b
+bool hb_launch_match_fused_selfcontained(const uint8_t *src, int typesize, void *desc, uint8_t *records, uint32_t nblk, int accel, hipStream_t s) {
+    const uint64_t items = (uint64_t)nblk * (uint64_t)typesize;
+    const unsigned grid = (unsigned)(items < 256u * 256u ? items : 256u * 256u);
+    switch (typesize) {
+    case 2: hipLaunchKernelGGL((k_match_fused<2, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel); return true;
+    case 4: hipLaunchKernelGGL((k_match_fused<4, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel); return true;
+    case 8: hipLaunchKernelGGL((k_match_fused<8, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel); return true;
+    default: return false;
+    }
+}
+
 int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
     const EncLayout L = enc_layout(a.n);
     uint8_t *w = a.work;
