@@ -373,3 +373,38 @@ func (fq *FrameQueue) Wait(ticket int64) (int, error) {
 	}
 	return int(n), nil
 }
+
+// ---------------------------------------------------------------------------------------------
+// C-Blosc-1 wire format (what README.md:20 promises; blosc.go has no code for it): frames c-blosc 1.x, python-blosc,
+// numcodecs read and write.  An extension next to CompressHIP / DecompressHIP, not a seam of the reference.
+// ---------------------------------------------------------------------------------------------
+
+// CompressCBlosc writes a C-Blosc-1 frame (LZ4 streams).  shuffle: NoShuffle, Shuffle or BitShuffle; len(data) < 2 GiB.
+func CompressCBlosc(data []byte, shuffle Shuffle, typeSize int) ([]byte, error) {
+	if !useHIP {
+		return nil, fmt.Errorf("%w: no HIP device", ErrCompressionFailed)
+	}
+	buf := make([]byte, int(C.hb_cblosc_bound(C.size_t(len(data)), C.int(typeSize))))
+	n := C.hb_cblosc_compress(ptr(data), C.size_t(len(data)), ptr(buf), C.size_t(len(buf)), C.int(shuffle), C.int(typeSize), C.int(Device))
+	if n < 0 {
+		return nil, hbError(n)
+	}
+	return buf[:n], nil
+}
+
+// DecompressCBlosc reads a C-Blosc-1 frame with LZ4 / LZ4HC streams (or a memcpyed one); other codec formats: ErrInvalidCodec.
+func DecompressCBlosc(frame []byte) ([]byte, error) {
+	if !useHIP {
+		return nil, fmt.Errorf("%w: no HIP device", ErrDecompressionFailed)
+	}
+	var h C.hb_cblosc_header
+	if rc := C.hb_cblosc_parse_header(ptr(frame), C.size_t(len(frame)), &h); rc != 0 {
+		return nil, hbError(C.int64_t(rc))
+	}
+	buf := make([]byte, int(h.nbytes))
+	n := C.hb_cblosc_decompress(ptr(frame), C.size_t(len(frame)), ptr(buf), C.size_t(len(buf)), C.int(Device))
+	if n < 0 {
+		return nil, hbError(n)
+	}
+	return buf[:n], nil
+}
