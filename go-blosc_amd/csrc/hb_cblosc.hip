@@ -127,6 +127,75 @@ __global__ void k_cb_bitunshuffle(uint8_t *__restrict__ dst, const uint8_t *__re
     }
 }
 
+// 8 x 8 bit transpose: out byte i, bit k = in byte k, bit i
+__device__ __forceinline__ uint64_t cb_transpose8(uint64_t x) {
+    uint64_t t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull; x ^= t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
+    return x;
+}
+// typesize 4, whole blocks of a multiple of 32 elements (what every writer's block size is): one thread per 32 elements -- 32 dword
+// loads (4 groups of every bit row at once), 8 x 16-byte stores -- instead of one byte per access
+template <bool FWD>
+__global__ void k_cb_bitshuffle4_fast(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t nfull, uint32_t blocksize) {
+    const uint32_t ng = blocksize / 32u, per = ng / 4u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)nfull * per; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i / per), q = (uint32_t)(i % per);
+        const size_t base = (size_t)b * blocksize;
+        if (!FWD) {
+            uint64_t x[4][4];                                                   // [byte j][group]: byte e = byte j of element 8 (4 q + group) + e
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t r[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) r[k] = ld4u(src + base + (size_t)(8 * j + k) * ng + 4u * q);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    uint64_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v |= (uint64_t)((r[k] >> (8 * g)) & 255u) << (8 * k);
+                    x[j][g] = cb_transpose8(v);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t w[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    w[e] = (uint32_t)((x[0][g] >> (8 * e)) & 255u) | ((uint32_t)((x[1][g] >> (8 * e)) & 255u) << 8) |
+                           ((uint32_t)((x[2][g] >> (8 * e)) & 255u) << 16) | ((uint32_t)((x[3][g] >> (8 * e)) & 255u) << 24);
+                u32x4 a, bb; a.x = w[0]; a.y = w[1]; a.z = w[2]; a.w = w[3]; bb.x = w[4]; bb.y = w[5]; bb.z = w[6]; bb.w = w[7];
+                st16u(dst + base + (size_t)(32u * q + 8u * g) * 4u, a);
+                st16u(dst + base + (size_t)(32u * q + 8u * g) * 4u + 16u, bb);
+            }
+        } else {
+            uint32_t r[4][8];                                                   // [byte j][bit k]: 4 bytes = groups 4 q .. 4 q + 3 of row 8 j + k
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) r[j][k] = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const u32x4 a = ld16u(src + base + (size_t)(32u * q + 8u * g) * 4u), bb = ld16u(src + base + (size_t)(32u * q + 8u * g) * 4u + 16u);
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint64_t v = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v |= (uint64_t)((w[e] >> (8 * j)) & 255u) << (8 * e);
+                    v = cb_transpose8(v);                                       // byte k = bit k of byte j of the 8 elements
+#pragma unroll
+                    for (int k = 0; k < 8; k++) r[j][k] |= (uint32_t)((v >> (8 * k)) & 255u) << (8 * g);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) st4u(dst + base + (size_t)(8 * j + k) * ng + 4u * q, r[j][k]);
+        }
+    }
+}
+
 __global__ void k_cb_result(const CbPlan *plan, hb_result *result, uint64_t nbytes) {
     result->flags = 1; result->total_bytes = nbytes; result->reserved = 0;
     if (plan->fail) { result->status = HB_ERR_DECOMPRESSION_FAILED; result->bytes = 0; }
@@ -370,7 +439,11 @@ int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, s
         hb_prof_begin("k_cb_unfilter", s);
         if (unshuf)
             hipLaunchKernelGGL(k_cb_unshuffle, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nbytes, blocksize, ts);
-        else
+        else if (ts == 4u && blocksize % 512u == 0u && nbytes >= blocksize) {       // whole blocks the fast way, a last shorter one the plain way
+            const uint32_t nfull = nbytes / blocksize, tail = nbytes - nfull * blocksize;
+            hipLaunchKernelGGL(k_cb_bitshuffle4_fast<false>, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nfull, blocksize);
+            if (tail) hipLaunchKernelGGL(k_cb_bitunshuffle, dim3(64), dim3(256), 0, s, (uint8_t *)d_dst + (size_t)nfull * blocksize, staged + (size_t)nfull * blocksize, tail, blocksize, ts);
+        } else
             hipLaunchKernelGGL(k_cb_bitunshuffle, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nbytes, blocksize, ts);
         hb_prof_end(s);
     }
@@ -420,7 +493,10 @@ int hb_cblosc_compress_dev(const void *d_src, size_t n, void *d_frame, size_t ca
         if (tail) hipLaunchKernelGGL(k_cb_shuffle, dim3(64), dim3(256), 0, s, filtered + (size_t)L.nfull * L.blocksize, (const uint8_t *)d_src + (size_t)L.nfull * L.blocksize, tail, L.blocksize, (uint32_t)typesize);
     } else if (unshuf || bits) {
         if (unshuf) hipLaunchKernelGGL(k_cb_shuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
-        else hipLaunchKernelGGL(k_cb_bitshuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
+        else if (typesize == 4 && L.blocksize % 512u == 0u && L.nfull) {
+            hipLaunchKernelGGL(k_cb_bitshuffle4_fast<true>, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, L.nfull, L.blocksize);
+            if (tail) hipLaunchKernelGGL(k_cb_bitshuffle, dim3(64), dim3(256), 0, s, filtered + (size_t)L.nfull * L.blocksize, (const uint8_t *)d_src + (size_t)L.nfull * L.blocksize, tail, L.blocksize, (uint32_t)typesize);
+        } else hipLaunchKernelGGL(k_cb_bitshuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
         fsrc = filtered;
     }
     hb_prof_end(s);
