@@ -62,7 +62,7 @@ __global__ void k_cb_plan(const uint8_t *__restrict__ frame, uint64_t n, uint32_
 // 4 KiB of output, older sources read back from HBM -- so that a dozen streams per CU are in flight.  (First version: the serial
 // block decoder with its 64 KiB history in LDS, one wavefront per CU: 21 GB/s on 256 MiB of float32.)
 __global__ __launch_bounds__(64) void k_cb_decode(const uint8_t *__restrict__ frame, CbPlan *plan, const CbStream *__restrict__ streams, uint32_t nstreams,
-                                                   uint8_t *dst) {
+                                                   uint8_t *dst, int small_elsewhere) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     __shared__ __attribute__((aligned(16))) uint8_t s_d[SY_IMG + 64];
@@ -72,12 +72,73 @@ __global__ __launch_bounds__(64) void k_cb_decode(const uint8_t *__restrict__ fr
         const CbStream st = streams[i];
         if (st.usize == 0u) continue;
         if (st.csize == st.usize) { wave_copy_g2g(dst + st.dst, frame + st.src, st.usize, lane); continue; }      // stored
+        if (small_elsewhere && st.usize <= HB_CHUNK) continue;            // k_cb_decode_small has it
         uint32_t out = st.dst;
         bool parked;
         const bool ok = sy_decode_unit<false>(frame + st.src, (uint64_t)st.csize, 0u, st.csize, st.dst, st.dst, out, dst, nullptr, s_win, s_tq, s_d, nullptr,
                                               lane, 1, 0u, 0u, nullptr, nullptr, nullptr, parked, st.dst + st.usize);
         if ((!ok || out != st.dst + st.usize) && lane == 0) atomicExch(&plan->fail, 1u);     // blosc_d: "nbytes != neblock -> -2"
         wave_sync();
+    }
+}
+
+// Streams of at most one chunk (what hb_cblosc_compress writes: every stream is a 4 KiB chunk of the matcher): stream and output both
+// fit into LDS, so the chunk decoder's machinery applies as it is -- window-parallel token parser, one token per lane, copies inside
+// the LDS image in dependency rounds (hb_dec_common.h) -- at 17 wavefronts per CU.  k_cb_decode leaves these streams alone.
+#define CB_SMALL HB_CHUNK
+__global__ __launch_bounds__(64) void k_cb_decode_small(const uint8_t *__restrict__ frame, CbPlan *plan, const CbStream *__restrict__ streams, uint32_t nstreams,
+                                                         uint8_t *__restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[CB_SMALL + 64 + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[CB_SMALL + 64];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    const int lane = threadIdx.x;
+    if (plan->fail) return;
+    for (uint32_t i = blockIdx.x; i < nstreams; i += gridDim.x) {
+        const CbStream st = streams[i];
+        if (st.usize == 0u || st.usize > CB_SMALL || st.csize == st.usize) continue;      // (stored streams: k_cb_decode copies them)
+        const uint8_t *g = frame + st.src;
+        const uint32_t sh = (uint32_t)((uintptr_t)g & 15u), slen = st.csize;           // slen < usize <= 4096
+        wave_sync();
+        {
+            const u32x4 *ga = (const u32x4 *)(g - sh);
+            const uint32_t nv = (sh + slen + 15u) >> 4;
+            for (uint32_t k = lane; k < nv; k += 64) ((u32x4 *)s_in)[k] = ga[k];
+        }
+        wave_sync();
+        uint32_t si = 0, di = 0, nq = 0;
+        bool ok = true, done = false;
+        while (ok && !done) {
+            const bool stop = dec_fill(s_in, sh, slen, slen, si, nq, s_tq, lane);
+            bool rewound = false;
+            if (!dec_drain(s_in + sh, 0, s_out, st.usize, 0u, di, si, nq, s_tq, stop, rewound, lane) || rewound) { ok = false; break; }      // (64 at a time; all of them when the parser stopped)
+            if (si == slen) { done = true; break; }
+            if (!stop) continue;
+            // one sequence the slow way: a length extension of several bytes, or the end of the stream
+            const uint32_t tok = RFL((uint32_t)s_in[sh + si]);
+            si++;
+            uint32_t ll = tok >> 4;
+            if (ll == 15u && !dec_read_ext(s_in, (int)sh, 0u, slen, g, slen, si, ll, lane)) { ok = false; break; }
+            if (ll > slen - si || ll > st.usize - di) { ok = false; break; }
+            for (uint32_t k = lane; k < ll; k += 64) s_out[di + k] = s_in[sh + si + k];
+            si += ll; di += ll;
+            if (si == slen) { if (tok & 15u) ok = false; done = true; break; }            // the final, literal-only sequence
+            if (slen - si < 2u) { ok = false; break; }
+            const uint32_t off = RFL((uint32_t)s_in[sh + si] | ((uint32_t)s_in[sh + si + 1u] << 8));
+            si += 2u;
+            uint32_t ml = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u && !dec_read_ext(s_in, (int)sh, 0u, slen, g, slen, si, ml, lane)) { ok = false; break; }
+            if (off == 0u || off > di || ml > st.usize - di) { ok = false; break; }
+            wave_sync();
+            dec_match_copy(s_out, di, off, ml, lane);
+            di += ml;
+            wave_sync();
+        }
+        if (!ok || di != st.usize) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
+        wave_sync();
+        uint8_t *o = dst + st.dst;
+        for (uint32_t k = (uint32_t)lane * 16u; k + 16u <= st.usize; k += 1024u) st16u(o + k, *(const u32x4 *)(s_out + k));
+        const uint32_t t0 = st.usize & ~15u;
+        if (t0 + (uint32_t)lane < st.usize) o[t0 + lane] = s_out[t0 + lane];
     }
 }
 
@@ -431,9 +492,15 @@ int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, s
     const bool filtered = unshuf || unbit;
     uint8_t *target = filtered ? staged : (uint8_t *)d_dst;
     const uint32_t nstreams = nblocks * nsplit;
-    hb_prof_begin("k_cb_decode", s);
+    hb_prof_begin("k_cb_plan", s);
     hipLaunchKernelGGL(k_cb_plan, dim3((nblocks + 63) / 64), dim3(64), 0, s, (const uint8_t *)d_frame, (uint64_t)n, nbytes, blocksize, hdr->cbytes, ts, flags, plan, streams);
-    hipLaunchKernelGGL(k_cb_decode, dim3(nstreams < 2048u ? nstreams : 2048u), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target);
+    const bool small = blocksize / nsplit <= HB_CHUNK;                   // streams of at most one chunk: the LDS-resident decoder takes them
+    hb_prof_end(s);
+    hb_prof_begin("k_cb_decode_small", s);
+    if (small) hipLaunchKernelGGL(k_cb_decode_small, dim3(nstreams < 65536u ? nstreams : 65536u), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target);
+    hb_prof_end(s);
+    hb_prof_begin("k_cb_decode", s);
+    hipLaunchKernelGGL(k_cb_decode, dim3(nstreams < 2048u ? nstreams : 2048u), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target, small ? 1 : 0);
     hb_prof_end(s);
     if (filtered) {
         hb_prof_begin("k_cb_unfilter", s);
