@@ -279,3 +279,21 @@ def test_random_valid_blocks_decode_exactly(hb, O):
         assert hb.lib().hb_last_result_flags() & 1, seed
         if not flags:
             assert hb.codecs[hb.LZ4].Decompress(block, n) == want, seed
+
+
+def test_many_small_random_blocks(hb, O):
+    # the same generator at sizes where every special path of the symbolic decoder sits close to the next one (regimes of 16-256 KiB:
+    # image slides, sequences that bypass the image, sources just in front of / behind a unit's first byte, parked copies)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import lz4_stream_gen as G
+    for seed in range(100, 124):
+        rng = np.random.default_rng(seed)
+        block, n = G.random_block(rng, (1 << 20) + seed * 4099, regime_len=(16 << 10) << (seed % 5))
+        want = O.lz4_decompress(np.frombuffer(block, np.uint8), n).tobytes()
+        assert len(want) == n
+        if len(block) >= (256 << 10):
+            frame = struct.pack("<BBBBIII", 2, hb.LZ4, 0, 1, n, n, 16 + len(block)) + block
+            assert hb.Decompress(frame) == want, seed
+            assert hb.lib().hb_last_result_flags() & 1, seed
+        assert hb.codecs[hb.LZ4].Decompress(block, n) == want, seed
