@@ -41,10 +41,11 @@
 #include "hb_lz4.h"
 #include <cstdlib>
 
-#ifndef HLOG
-#define HLOG 8
+#ifndef HLOG_HC
+#define HLOG_HC 8
 #endif
-#define HSIZE (1u << HLOG)
+#define HLOGW(WAYS) ((WAYS) == 1 ? 8 : HLOG_HC)      // log2 of the hash table's buckets: LZ4 / LZ4HC
+#define HSIZEW(WAYS) (1u << HLOGW(WAYS))
 #define LITCAP 32u          // literal runs up to this long are copied by the owning lane, longer ones by the wave
 
 struct __attribute__((aligned(16))) ChunkDesc {
@@ -160,7 +161,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
     {
         {
             u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-            for (uint32_t i = lane; i < HSIZE * WAYS * 2 / 16; i += 64) ((u32x4 *)s_tab)[i] = z;
+            for (uint32_t i = lane; i < HSIZEW(WAYS) * WAYS * 2 / 16; i += 64) ((u32x4 *)s_tab)[i] = z;
             if (lane < 2) ((u32x4 *)s_st)[lane] = z;
         }
         wave_sync();
@@ -412,7 +413,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             // the table is keyed by FIVE bytes (one v_and + one v_mad_u32_u24 more than a 4-byte key): the entry of a 4-gram that
             // occurs in many contexts is then not the latest of them but the latest with the same next byte -- longer matches, 20 %
             // fewer sequences and a better ratio at the same table size (modelled in tests/tools/gpu_lz4_model.c)
-            const uint32_t h = ((v + (v4 & 255u) * 0x50505u) * 2246822519u) >> (32 - HLOG);
+            const uint32_t h = ((v + (v4 & 255u) * 0x50505u) * 2246822519u) >> (32 - HLOGW(WAYS));
             uint32_t cand, xa, xb, ac = 0, hc_fbit = 0;
             const uint32_t *wc = nullptr;
             uint32_t c3 = 0;
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
                                               uint32_t nchunks, int bits4, int keep_long, int accel) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE * WAYS];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
                                                     uint8_t *__restrict__ records, uint32_t nblk, uint32_t plane_mask, int accel) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZE * WAYS];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
     __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
