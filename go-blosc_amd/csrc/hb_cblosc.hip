@@ -57,22 +57,30 @@ __global__ void k_cb_plan(const uint8_t *__restrict__ frame, uint64_t n, uint32_
     if (bad) atomicExch(&plan->fail, 1u);
 }
 
+#define CB_SMALL_IN 3072u        // longest stream k_cb_decode_small stages (see there)
 // ---- one wavefront per stream ----
 // The decoder is pass A of the symbolic decoder without the symbols (hb_sym_decode.h): 13 KiB of LDS per wavefront -- an image of the last
 // 4 KiB of output, older sources read back from HBM -- so that a dozen streams per CU are in flight.  (First version: the serial
 // block decoder with its 64 KiB history in LDS, one wavefront per CU: 21 GB/s on 256 MiB of float32.)
 __global__ __launch_bounds__(64) void k_cb_decode(const uint8_t *__restrict__ frame, CbPlan *plan, const CbStream *__restrict__ streams, uint32_t nstreams,
-                                                   uint8_t *dst, int small_elsewhere) {
+                                                   uint8_t *dst, int small_elsewhere, uint32_t P) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     __shared__ __attribute__((aligned(16))) uint8_t s_d[SY_IMG + 64];
     const int lane = threadIdx.x;
     if (plan->fail) return;
-    for (uint32_t i = blockIdx.x; i < nstreams; i += gridDim.x) {
-        const CbStream st = streams[i];
+    // stream order: see k_cb_decode_small (stream i is byte plane i % typesize of its block, workgroup i runs on XCD i % 8, and the
+    // planes differ several times in cost); one stream per workgroup up to 65536 streams, so that a finished cheap stream makes
+    // room for the next one
+    const uint32_t mgrp = (nstreams + 7u) / 8u;
+    for (uint32_t it = blockIdx.x; it < mgrp * 8u; it += gridDim.x) {
+        const uint32_t i = (uint32_t)(((uint64_t)(it >> 3) * P) % mgrp) * 8u + ((it + (it >> 3) + it / gridDim.x) & 7u);
+        if (i >= nstreams) continue;
+        CbStream st = streams[i];                                              // wave-uniform, but it comes out of a vector load: to scalar registers
+        st.src = RFL(st.src); st.csize = RFL(st.csize); st.dst = RFL(st.dst); st.usize = RFL(st.usize);
         if (st.usize == 0u) continue;
         if (st.csize == st.usize) { wave_copy_g2g(dst + st.dst, frame + st.src, st.usize, lane); continue; }      // stored
-        if (small_elsewhere && st.usize <= HB_CHUNK) continue;            // k_cb_decode_small has it
+        if (small_elsewhere && st.usize <= HB_CHUNK && st.csize <= CB_SMALL_IN) continue;   // k_cb_decode_small has it
         uint32_t out = st.dst;
         bool parked;
         const bool ok = sy_decode_unit<false>(frame + st.src, (uint64_t)st.csize, 0u, st.csize, st.dst, st.dst, out, dst, nullptr, s_win, s_tq, s_d, nullptr,
@@ -87,15 +95,22 @@ __global__ __launch_bounds__(64) void k_cb_decode(const uint8_t *__restrict__ fr
 // the LDS image in dependency rounds (hb_dec_common.h) -- at 17 wavefronts per CU.  k_cb_decode leaves these streams alone.
 #define CB_SMALL HB_CHUNK
 __global__ __launch_bounds__(64) void k_cb_decode_small(const uint8_t *__restrict__ frame, CbPlan *plan, const CbStream *__restrict__ streams, uint32_t nstreams,
-                                                         uint8_t *__restrict__ dst) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[CB_SMALL + 64 + 128];
+                                                         uint8_t *__restrict__ dst, uint32_t P) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[CB_SMALL_IN + 64 + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[CB_SMALL + 64];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     const int lane = threadIdx.x;
     if (plan->fail) return;
-    for (uint32_t i = blockIdx.x; i < nstreams; i += gridDim.x) {
-        const CbStream st = streams[i];
-        if (st.usize == 0u || st.usize > CB_SMALL || st.csize == st.usize) continue;      // (stored streams: k_cb_decode copies them)
+    // stream order as in k_dec_indexed (hb_lz4_dec.hip): the streams of a split block are its byte planes, stream i = plane i % typesize,
+    // and workgroup i runs on XCD i % 8 -- in stream order two XCDs would get all the streams of the token-dense plane (measured: 3.1 ms
+    // against 1.5).  Workgroup (step k = it / 8, XCD x = it % 8) takes stream 8 * (k * P mod m) + (x + k) % 8; grid a multiple of 8.
+    const uint32_t mgrp = (nstreams + 7u) / 8u;
+    for (uint32_t it = blockIdx.x; it < mgrp * 8u; it += gridDim.x) {
+        const uint32_t i = (uint32_t)(((uint64_t)(it >> 3) * P) % mgrp) * 8u + ((it + (it >> 3) + it / gridDim.x) & 7u);
+        if (i >= nstreams) continue;
+        CbStream st = streams[i];                                              // wave-uniform, but it comes out of a vector load: to scalar registers
+        st.src = RFL(st.src); st.csize = RFL(st.csize); st.dst = RFL(st.dst); st.usize = RFL(st.usize);
+        if (st.usize == 0u || st.usize > CB_SMALL || st.csize == st.usize || st.csize > CB_SMALL_IN) continue;      // (stored streams: k_cb_decode copies them)
         const uint8_t *g = frame + st.src;
         const uint32_t sh = (uint32_t)((uintptr_t)g & 15u), slen = st.csize;           // slen < usize <= 4096
         wave_sync();
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(64) void k_cb_decode_small(const uint8_t *__restric
         while (ok && !done) {
             const bool stop = dec_fill(s_in, sh, slen, slen, si, nq, s_tq, lane);
             bool rewound = false;
-            if (!dec_drain(s_in + sh, 0, s_out, st.usize, 0u, di, si, nq, s_tq, stop, rewound, lane) || rewound) { ok = false; break; }      // (64 at a time; all of them when the parser stopped)
+            if (!dec_drain(s_in, (int)sh, s_out, st.usize, 0u, di, si, nq, s_tq, stop, rewound, lane) || rewound) { ok = false; break; }      // (64 at a time; all of them when the parser stopped)
             if (si == slen) { done = true; break; }
             if (!stop) continue;
             // one sequence the slow way: a length extension of several bytes, or the end of the stream
@@ -496,11 +511,24 @@ int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, s
     hipLaunchKernelGGL(k_cb_plan, dim3((nblocks + 63) / 64), dim3(64), 0, s, (const uint8_t *)d_frame, (uint64_t)n, nbytes, blocksize, hdr->cbytes, ts, flags, plan, streams);
     const bool small = blocksize / nsplit <= HB_CHUNK;                   // streams of at most one chunk: the LDS-resident decoder takes them
     hb_prof_end(s);
+    const uint32_t mgrp = (nstreams + 7u) / 8u;
+    uint32_t P = mgrp / 4u + 1u;                                        // coprime to the groups of 8 streams, about a quarter turn
+    for (;; P++) { uint32_t x = P, y = mgrp; while (y) { const uint32_t t = x % y; x = y; y = t; } if (x == 1u) break; }
+    const unsigned grid = mgrp * 8u < 65536u ? mgrp * 8u : 65536u;
     hb_prof_begin("k_cb_decode_small", s);
-    if (small) hipLaunchKernelGGL(k_cb_decode_small, dim3(nstreams < 65536u ? nstreams : 65536u), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target);
+    if (small) hipLaunchKernelGGL(k_cb_decode_small, dim3(grid), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target, P);
     hb_prof_end(s);
     hb_prof_begin("k_cb_decode", s);
-    hipLaunchKernelGGL(k_cb_decode, dim3(nstreams < 2048u ? nstreams : 2048u), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target, small ? 1 : 0);
+    // (long streams: as many passes per workgroup as a block has streams, fewer while that leaves under 2048 workgroups -- with the
+    // rotation by the pass number a workgroup decodes one stream of each plane, and all workgroups live about equally long; see
+    // k_cb_decode_small)
+    unsigned gbig = grid;
+    if (!small && nsplit > 1u) {
+        unsigned p = nsplit;
+        while (p > 1u && mgrp * 8u / p < 2048u) p >>= 1;
+        gbig = (mgrp * 8u / p + 7u) / 8u * 8u;
+    }
+    hipLaunchKernelGGL(k_cb_decode, dim3(gbig), dim3(64), 0, s, (const uint8_t *)d_frame, plan, streams, nstreams, target, small ? 1 : 0, P);
     hb_prof_end(s);
     if (filtered) {
         hb_prof_begin("k_cb_unfilter", s);

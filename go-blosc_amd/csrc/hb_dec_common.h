@@ -10,7 +10,7 @@ struct DecPlan {
     uint32_t nunits;
     uint32_t nbytes;      // decoded size the index declares
     uint32_t post;        // set by k_dec_serial when it decoded into the staging buffer: the gated un-filter must run
-    uint32_t stride;      // unit order of the indexed decoder: u = i * stride mod nunits, gcd(stride, nunits) == 1
+    uint32_t stride;      // unit order of the indexed decoder (k_dec_indexed): coprime to the number of groups of 8 units
     uint32_t pad[2];
 };
 enum { DEC_SERIAL = 0, DEC_INDEXED = 1 };

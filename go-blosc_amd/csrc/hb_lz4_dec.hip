@@ -50,9 +50,11 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
     if (h[3] != HB_CHUNK || nunits != ((uint64_t)h[5] + HB_CHUNK - 1) / HB_CHUNK) return;
     plan->nunits = (uint32_t)nunits;
     plan->nbytes = h[5];
-    uint32_t P = (uint32_t)nunits / 4u + 1u;                 // about a quarter turn per step (next byte plane of a shuffled frame)
+    // unit order of the un-fused launch (see k_dec_indexed): a quarter turn per step through the groups of 8 units
+    const uint32_t m = ((uint32_t)nunits + 7u) / 8u;
+    uint32_t P = m / 4u + 1u;
     for (;;) {
-        uint32_t x = P, y = (uint32_t)nunits;
+        uint32_t x = P, y = m;
         while (y) { const uint32_t t = x % y; x = y; y = t; }
         if (x == 1u) break;
         P++;
@@ -83,16 +85,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     const uint8_t *ent = index + HB_IDX_HDR_BYTES;
     const uint32_t nbytes = plan->nbytes;
 
-    // Units are visited in a scrambled order (u = i * P mod nunits, P odd-ish and coprime to nunits, about
-    // nunits/4): neighbouring workgroups then work on far-apart parts of the buffer (different byte planes of a
-    // shuffled frame: issue-bound token-dense units next to bandwidth-bound literal-only ones), and the odd grid
-    // size rotates the mix from pass to pass.  Any order is correct: units are independent.
+    // Unit order.  Workgroups are placed on the 8 XCDs round-robin (workgroup i -> XCD i % 8), and the byte planes of a shuffled
+    // frame differ 3x in cost and are contiguous quarters of the unit range: an order in which workgroup i takes plane i % 4
+    // (the obvious "next plane per workgroup" scramble) gives every plane to TWO of the eight XCDs for the whole launch, and the
+    // launch lasts as long as the two with the token-dense plane need (measured: 2.28 ms against 1.41 for the same work).  So:
+    // workgroup `it` = (step k = it / 8, XCD x = it % 8) takes unit 8 * (k * P mod m) + (x + k) % 8, m = groups of 8 units,
+    // P coprime to m and about m / 4: every XCD walks the whole buffer a quarter turn per step (its resident waves are an even
+    // mix of all planes: issue-bound token-dense units next to bandwidth-bound literal ones), and the rotation by k takes
+    // it through all residues mod 8 (streams that interleave planes with period 2 / 4 / 8 -- hb_cblosc.hip -- stay balanced
+    // too).  The grid is a multiple of 8, so the XCD of a workgroup does not change from pass to pass.  Any order is correct:
+    // units are independent.
     const uint32_t P = plan->stride;                        // computed once by k_dec_plan
-    for (uint32_t it = blockIdx.x; it < nunits; it += gridDim.x) {
-        uint32_t u = (uint32_t)(((uint64_t)it * P) % nunits);
-        // (the plane-rotating order below visits every unit exactly once only when the grid is a multiple of 8 * ush or
-        // covers all units in one pass; any other launch shape keeps the plain bijection above)
-        if (ush && nunits % (uint32_t)ush == 0u && (gridDim.x % (8u * (uint32_t)ush) == 0u || gridDim.x >= nunits)) {
+    const uint32_t mgrp = (nunits + 7u) / 8u;
+    for (uint32_t it = blockIdx.x; it < mgrp * 8u; it += gridDim.x) {
+        uint32_t u = (uint32_t)(((uint64_t)(it >> 3) * P) % mgrp) * 8u + ((it + (it >> 3)) & 7u);
+        const bool fused_order = ush && nunits % (uint32_t)ush == 0u && (gridDim.x % (8u * (uint32_t)ush) == 0u || gridDim.x >= nunits);
+        if (fused_order ? it >= nunits : u >= nunits) continue;
+        if (fused_order) {
             // fused un-shuffle: the `ush` units that make up one 4096-element block write interleaved bytes of the same
             // lines, so they get workgroup ids that are equal mod 8 (same XCD under round-robin placement: the
             // partial lines meet in one L2) and run close in time; the plane rotates with the pass (planes differ in
@@ -359,8 +368,9 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s) {
     if (index) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
         // a few units per workgroup (measured on 1 GiB: 16384 workgroups 1.84 ms, 65536 1.70 ms, 131072 2.09 ms, one unit per
-        // workgroup 3.56 ms); odd when capped, so that the scrambled order rotates the mix of planes from pass to pass
-        unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 256u + 1u ? units : 256u * 256u + 1u));
+        // workgroup 3.56 ms); a multiple of 8: a workgroup stays on its XCD from pass to pass (unit order in the kernel)
+        const uint64_t units8 = (units + 7) / 8 * 8;
+        unsigned grid = (unsigned)(units8 < 8 ? 8 : (units8 < 256u * 256u ? units8 : 256u * 256u));
         if (a.fused_unshuffle_ts && units > 256u * 16u) {
             // fused un-shuffle, beyond 16 MiB: `typesize` passes per workgroup where possible (it then meets every plane
             // once), and a multiple of 8 * typesize (see the unit order in the kernel)
