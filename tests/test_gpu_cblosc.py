@@ -167,3 +167,15 @@ def test_a_large_frame(hb, O, cb):
     assert got == x.tobytes()
     h = hb.CBloscParseHeader(f)
     print(f"C-Blosc-1 frame, 256 MiB f32 shuffle+lz4 (blocksize {h.blocksize}, ratio {len(f) / x.size:.3f}): {x.size / dt / 1e9:.2f} GB/s host->host")
+
+
+def test_more_streams_than_workgroups_and_a_ragged_tail(hb, O):
+    # the stream order of the decoders (hb_cblosc.hip k_cb_decode_small / k_cb_decode: 8 * (k P mod m) + (x + k + pass) mod 8) has to
+    # visit every stream exactly once also when there are several passes per workgroup and the stream count is no multiple of 8:
+    # 300 MiB + 4 KiB + 13 bytes of float32 written here = 19201 blocks = 76804 streams (one of them the short, unsplit last block)
+    n = (300 << 20) + 4096 + 13
+    x = np.frombuffer(O.synth(O.D_F32, n // 4 + 1).tobytes()[:n], np.uint8)
+    f = hb.CBloscCompress(x.tobytes(), 1, 4)
+    h = hb.CBloscParseHeader(f)
+    assert h.blocksize == 16384 and h.nbytes == n
+    assert hb.CBloscDecompress(f) == x.tobytes()

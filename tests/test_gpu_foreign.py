@@ -297,3 +297,21 @@ def test_many_small_random_blocks(hb, O):
             assert hb.Decompress(frame) == want, seed
             assert hb.lib().hb_last_result_flags() & 1, seed
         assert hb.codecs[hb.LZ4].Decompress(block, n) == want, seed
+
+
+def test_unit_order_of_the_unfused_decoder_covers_ragged_multi_pass_frames(hb, O):
+    # k_dec_indexed without a fused un-filter visits unit 8 * (k P mod m) + (x + k) mod 8 (hb_lz4_dec.hip): every unit exactly once also
+    # with several passes per workgroup (more than 65536 units) and a unit count that is no multiple of 8 -- 300 MiB + 4 KiB + 13
+    # bytes of already shuffled float32, no filter (76802 units), with the stored index and with the rebuilt one
+    n = (300 << 20) + 4096 + 13
+    x = np.ascontiguousarray(O.filter(O.OP_SHUFFLE, O.synth(O.D_F32, n // 4 + 1), 4)[:n])   # byte planes: compressible without a filter
+    L = hb.lib()
+    for opts in (hb.OPT_INDEX_TRAILER, 0):
+        cap = L.hb_frame_bound(n) + (n // 4096 + 4) * 16 + 64
+        out = np.empty(cap, np.uint8)
+        c = L.hb_compress_frame(x.ctypes.data, n, out.ctypes.data, cap, hb.LZ4, 5, hb.NoShuffle, 1, opts, 0)
+        assert c > 0
+        back = np.zeros(n, np.uint8)
+        assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, n, 0, 0) == n
+        assert L.hb_last_result_flags() & 1
+        assert np.array_equal(back, x), opts
