@@ -8,8 +8,8 @@
 #define RG_DENSE    128u
 #define RG_BUCKETS  128u
 #define RG_INVALID  0xFFFFFFFFu
-#define RG_MAXREG   8192u
-#define RG_MINREG   65536u        // smallest region, stream bytes
+#define RG_MAXREG   16384u
+#define RG_MINREG   32768u        // smallest region, stream bytes
 #define RG_PWIN     8192u         // parse window
 #define RG_FIXROUNDS 16            // k_rg_settle launches (each iterates to a standstill; idle once settled), re-parses in between
 #define RG_FPARSERS 2             // wavefronts of the last settle launch that parse (LDS: the regions' state takes 128 KiB)

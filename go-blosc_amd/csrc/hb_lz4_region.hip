@@ -284,7 +284,9 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
 // ask for it itself (RG_FPARSERS wavefronts) and goes on, until nothing moves or RG_MAXHOPS.
 template <bool FINISH>
 __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces) {
-    __shared__ uint32_t s_entry[RG_MAXREG], s_exit[RG_MAXREG], s_outl[RG_MAXREG], s_need[RG_MAXREG];
+    // (LDS: entry + exit of every region, one bit per region for "waits for a full parse"; output lengths stay in global memory --
+    // they are written a few times per launch, read never)
+    __shared__ uint32_t s_entry[RG_MAXREG], s_exit[RG_MAXREG], s_needb[RG_MAXREG / 32];
     __shared__ uint32_t s_pm[1024];
     __shared__ uint32_t s_changed, s_pend, s_nlist;
     __shared__ __attribute__((aligned(16))) uint8_t s_pwin[FINISH ? RG_FPARSERS : 1][FINISH ? RG_PWIN + 128 : 16];
@@ -294,11 +296,15 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
     const uint32_t nreg = plan->nreg, bsh = plan->pad[0], rs = plan->rs;
     if (plan->pad[2]) return;                                           // an earlier launch came to a standstill with nothing pending
     constexpr uint32_t PER = RG_MAXREG / 1024;
+    auto need = [&](uint32_t r) __attribute__((always_inline)) -> bool { return (s_needb[r >> 5] >> (r & 31u)) & 1u; };
+    auto set_need = [&](uint32_t r, bool v) __attribute__((always_inline)) { if (v) atomicOr(&s_needb[r >> 5], 1u << (r & 31u)); else atomicAnd(&s_needb[r >> 5], ~(1u << (r & 31u))); };
+    for (uint32_t k = (uint32_t)t; k < RG_MAXREG / 32; k += 1024u) s_needb[k] = 0u;
+    if (t == 0) { s_changed = 0; s_pend = 0; s_nlist = 0; }
+    __syncthreads();
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t r = (uint32_t)t * PER + k;
-        if (r < nreg) { s_entry[r] = reg[r].entry; s_exit[r] = reg[r].exit; s_outl[r] = reg[r].outlen; s_need[r] = reg[r].needfull; }
+        if (r < nreg) { s_entry[r] = reg[r].entry; s_exit[r] = reg[r].exit; if (reg[r].needfull) atomicOr(&s_needb[r >> 5], 1u << (r & 31u)); }
     }
-    if (t == 0) { s_changed = 0; s_pend = 0; s_nlist = 0; }
     __syncthreads();
     bool capped = true;                                                 // left the loop because of the iteration cap, still moving
   for (int hop = 0; hop < (FINISH ? RG_MAXHOPS : 1); hop++) {
@@ -322,13 +328,13 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
             if (r >= nreg) break;
             const uint32_t a = run, rb = r * rs;                        // (= reg[r].b)
             bool work = r != 0u && a >= rb;                             // (a < b: no predecessor reaches me yet -- unsettled exits in front of me)
-            if (work && s_need[r] && s_entry[r] == a) work = false;     // a full parse from this entry is already pending
+            if (work && need(r) && s_entry[r] == a) work = false;     // a full parse from this entry is already pending
             if (work && s_entry[r] == a && s_exit[r] != RG_INVALID) work = false;      // belief unchanged
             if (work) {
                 const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)(r + 1) * rs : n_src;
                 s_entry[r] = a;
                 s_changed = 1;
-                if ((uint64_t)a >= bnext) { s_exit[r] = a; s_outl[r] = 0; s_need[r] = 0; }     // no token of the chain starts in this region
+                if ((uint64_t)a >= bnext) { s_exit[r] = a; reg[r].outlen = 0; set_need(r, false); }     // no token of the chain starts in this region
                 else {
                     const uint2 *tr = traces + (size_t)r * RG_TRACE;
                     const uint32_t nt = reg[r].ntrace, exit0 = reg[r].exit0, outlen0 = reg[r].outlen0;
@@ -336,14 +342,14 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
                     uint32_t ti = 0;
                     bool settled = false;
                     for (int iter = 0; iter < RG_WALKCAP && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a wave-parallel re-parse)
-                        if (p >= bnext) { s_exit[r] = (uint32_t)p; s_outl[r] = (uint32_t)cum; s_need[r] = 0; settled = true; break; }
+                        if (p >= bnext) { s_exit[r] = (uint32_t)p; reg[r].outlen = (uint32_t)cum; set_need(r, false); settled = true; break; }
                         // merged with the recorded parse?  (one of its first tokens, or the first token of a bucket: once the parses have
                         // merged, this walk visits every token of the recorded one, so it meets a recorded position within a bucket)
                         while (ti < nt && tr[ti].x < (uint32_t)p) ti++;
                         uint32_t cum0 = RG_INVALID;
                         if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
                         else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
-                        if (cum0 != RG_INVALID) { s_exit[r] = exit0; s_outl[r] = (uint32_t)(cum + (outlen0 - cum0)); s_need[r] = 0; reg[r].pad0 = (uint32_t)p; settled = true; break; }
+                        if (cum0 != RG_INVALID) { s_exit[r] = exit0; reg[r].outlen = (uint32_t)(cum + (outlen0 - cum0)); set_need(r, false); reg[r].pad0 = (uint32_t)p; settled = true; break; }
                         // one token, serially
                         const uint32_t tok = src[p];
                         uint64_t q = p + 1, ll = tok >> 4;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
                         cum += ll + ml;
                         p = q;
                     }
-                    if (!settled) { s_exit[r] = RG_INVALID; s_need[r] = 1; s_pend = 1; }     // k_rg_parse takes it from `entry`
+                    if (!settled) { s_exit[r] = RG_INVALID; set_need(r, true); s_pend = 1; }     // k_rg_parse takes it from `entry`
                 }
             }
             if (s_exit[r] != RG_INVALID && s_exit[r] != s_entry[r]) run = max(run, s_exit[r]);
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
         // the regions that wait for a parse: listed, handed to the parser wavefronts through global memory, results read back
         for (uint32_t k = 0; k < PER; k++) {
             const uint32_t r = (uint32_t)t * PER + k;
-            if (r < nreg && s_need[r]) { const uint32_t i = atomicAdd(&s_nlist, 1u); if (i < RG_FLIST) { s_list[i] = r; reg[r].entry = s_entry[r]; reg[r].needfull = 1; } }
+            if (r < nreg && need(r)) { const uint32_t i = atomicAdd(&s_nlist, 1u); if (i < RG_FLIST) { s_list[i] = r; reg[r].entry = s_entry[r]; reg[r].needfull = 1; } }
         }
         __threadfence_block();
         __syncthreads();
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
         __syncthreads();
         if ((uint32_t)t < nl) {
             const uint32_t r = s_list[t];
-            s_exit[r] = __builtin_nontemporal_load(&reg[r].exit); s_outl[r] = __builtin_nontemporal_load(&reg[r].outlen); s_need[r] = 0;
+            s_exit[r] = __builtin_nontemporal_load(&reg[r].exit); set_need(r, false);           // (the parser wrote reg[r].outlen itself)
         }
         if (t == 0) { s_nlist = 0; s_pend = 0; s_changed = 0; }
         __syncthreads();
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
   }
     for (uint32_t k = 0; k < PER; k++) {
         const uint32_t r = (uint32_t)t * PER + k;
-        if (r < nreg) { reg[r].entry = s_entry[r]; reg[r].exit = s_exit[r]; reg[r].outlen = s_outl[r]; reg[r].needfull = s_need[r]; }
+        if (r < nreg) { reg[r].entry = s_entry[r]; reg[r].exit = s_exit[r]; reg[r].needfull = need(r) ? 1u : 0u; }
     }
     if (t == 0) { plan->pad[1] = s_pend; if (!s_pend && !capped) plan->pad[2] = 1; }   // parses pending: the next k_rg_parse has work; else: settled
 }

@@ -78,7 +78,17 @@ __global__ __launch_bounds__(64) void k_sy_units(const RgPlan *rg, const RgRegio
     const uint32_t nreg = rg->nreg;
     for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
         const RgRegion R = reg[r];
-        const uint32_t entry = R.entry, exitp = R.exit, L = R.outlen, O = (uint32_t)R.opos;
+        uint32_t entry = R.entry, exitp = R.exit, L = R.outlen;
+        const uint32_t O = (uint32_t)R.opos;
+        // two neighbouring light regions make ONE unit (the even one gets it, the odd one stays empty): the discovery likes its regions
+        // small -- a region is one wavefront's serial parse -- but every unit costs pass B a 64 Ki-entry map (k_sy_compose)
+        if ((r ^ 1u) < nreg) {
+            const uint32_t Lm = reg[r ^ 1u].outlen;
+            if ((uint64_t)L + Lm <= SY_HEAVY) {
+                if (r & 1u) { entry = exitp; L = 0u; }
+                else { exitp = reg[r ^ 1u].exit; L += Lm; }
+            }
+        }
         SyUnit *u = un + (size_t)r * SY_SUB;
         wave_sync();
         if ((uint32_t)lane <= SY_SUB) { s_e[lane] = exitp; s_o[lane] = O + L; }

@@ -21,7 +21,7 @@ import hipblosc as hb
 import bench
 import oracle as O
 
-RG_MAXREG, REG_BYTES = 8192, 64
+RG_MAXREG, REG_BYTES = 16384, 64
 
 
 def main():
