@@ -10,7 +10,8 @@
 #define RG_INVALID  0xFFFFFFFFu
 #define RG_MAXREG   16384u
 #define RG_MINREG   32768u        // smallest region, stream bytes
-#define RG_PWIN     8192u         // parse window
+#define RG_PWIN     4096u         // parse window: every kernel that walks tokens is bound by one wavefront's latency, so its throughput is the number
+                                  // of resident waves -- 4 KiB gives k_rg_parse / k_rg_index 32 per CU (8 KiB: 17; index-less 1 GiB decode 5.1 -> 4.6 ms)
 #define RG_FIXROUNDS 16            // k_rg_settle launches (each iterates to a standstill; idle once settled), re-parses in between
 #define RG_FPARSERS 2             // wavefronts of the last settle launch that parse (LDS: the regions' state takes 128 KiB)
 #define RG_FLIST    64            // regions it hands them per hop
