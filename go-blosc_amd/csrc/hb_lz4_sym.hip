@@ -18,8 +18,8 @@
 //   pass B  the 65535 bytes in front of a unit are the tail of its predecessors, themselves symbolic: the tail of unit r as a
 //           function of the tail in front of it is a MAP of 65535 entries {value | reference}, maps compose associatively, so the
 //           tails are resolved by a scan over the units: k_sy_compose (per group of units: the composed map, sequential inside
-//           the group, groups in parallel), k_sy_chain (one workgroup: the resolved tail in front of every group, one map per step,
-//           the tail in LDS), k_sy_tails (per group again: every unit's last 64 KiB resolved against a 64 KiB ring in LDS that
+//           the group, 256 groups in parallel), k_sy_scan + k_sy_front (an inclusive scan over the group maps, one launch per
+//           doubling step: the resolved tail in front of every group), k_sy_tails (per group again: every unit's last 64 KiB resolved against a 64 KiB ring in LDS that
 //           rolls forward), k_sy_resolve (all the other bytes, in pieces over the whole chip: the 64 KiB in front of a unit are
 //           final by then and are read back into LDS; one byte gather per reference).
 //
@@ -29,7 +29,7 @@
 #include "hb_sym_decode.h"
 
 #define SY_W        65536u        // entries of a tail map / bytes of a tail image (index = distance 1..65535; entry 0 unused)
-#define SY_GROUPS   128u          // groups of regions in pass B
+#define SY_GROUPS   256u          // groups of units in pass B (128: k_sy_compose 1.9 ms, 256: 1.05, 512: 1.0 but the scan over the groups 0.4)
 #define SY_SUB      8u            // a region with more than SY_HEAVY bytes of output is decoded in this many parts
 #define SY_HEAVY    (1u << 20)
 #define SY_MAXUNITS (RG_MAXREG * SY_SUB)
@@ -46,7 +46,7 @@ static inline SyLayout sy_layout(size_t n_out) {
     auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
     const uint32_t g = sy_max_groups(n_out);
     L.plan = take(sizeof(SyPlan));
-    L.par = take((size_t)SY_GROUPS * 4);
+    L.par = take((size_t)SY_GROUPS * 4 * 2);                  // which of a group's two map buffers is current: two arrays, k_sy_scan flips between them
     L.units = take((size_t)SY_MAXUNITS * sizeof(SyUnit));
     L.list = take((size_t)SY_MAXUNITS * 4);
     L.big = take((size_t)SY_MAXUNITS * sizeof(SyBig));
@@ -254,42 +254,47 @@ __global__ __launch_bounds__(1024) void k_sy_compose(const SyUnit *__restrict__ 
     if (t == 0) par[g] = (cur == maps + (size_t)g * 2 * SY_W) ? 0u : 1u;
 }
 
-// tails[g][d] = the final byte d positions in front of group g's first output byte (d = 1..65535)
-__global__ __launch_bounds__(1024) void k_sy_chain(const SyPlan *sy, const uint32_t *__restrict__ maps, const uint32_t *__restrict__ par, uint8_t *__restrict__ tails) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_f[SY_W];
+// tails[g][d] = the final byte d positions in front of group g's first output byte (d = 1..65535), for every group: an inclusive scan over the group maps (Hillis-Steele, one launch per round: after the round
+// with `step` the map of group g covers the groups (g - 2 step, g]), then every group reads the bytes in front of it off its
+// predecessor's scanned map.  Composition of an earlier span A with a later one B: the byte d from the end of B is B[d] if that is a
+// value, else the byte (reference) in front of B = that far from the end of A.  A group's two map buffers take turns (par_in / par_out
+// say which is current); the workgroup of g + step reads group g's current buffer while g's own workgroup writes the other.
+// (First version: one workgroup that walked the groups front to back, the resolved tail in LDS -- 127 dependent steps, 1.6 ms; the scan: 0.1-0.2.)
+__global__ __launch_bounds__(1024) void k_sy_scan(const SyPlan *sy, uint32_t *maps, const uint32_t *__restrict__ par_in, uint32_t *__restrict__ par_out, uint32_t step) {
     if (!sy->go || sy->fail) return;
+    const uint32_t g = blockIdx.x;
+    if (g >= sy->groups) return;
     const int t = threadIdx.x;
-    const uint32_t G = sy->groups;
-    u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-    for (int q = 0; q < 4; q++) ((u32x4 *)s_f)[t * 4 + q] = z;         // nothing in front of the block (never referenced: pass A checked)
-    __syncthreads();
-    // the map of group g is fetched while the tail in front of group g is still being written (the maps are all there: k_sy_compose is done)
-    u32x4 e[16];
-    if (G > 1u) {
-        const u32x4 *m = (const u32x4 *)(maps + ((size_t)0 * 2 + par[0]) * SY_W) + (size_t)t * 16;
+    const uint32_t pg = par_in[g];
+    if (g < step) { if (t == 0) par_out[g] = pg; return; }             // covers everything in front of it already
+    const uint32_t *__restrict__ B = maps + ((size_t)g * 2 + pg) * SY_W;
+    const uint32_t *__restrict__ A = maps + ((size_t)(g - step) * 2 + par_in[g - step]) * SY_W;
+    uint32_t *__restrict__ N = maps + ((size_t)g * 2 + (pg ^ 1u)) * SY_W;
+    for (uint32_t d0 = 0; d0 < SY_W; d0 += 8192u) {
+        uint32_t e[8];
 #pragma unroll
-        for (int q = 0; q < 16; q++) e[q] = m[q];
+        for (int q = 0; q < 8; q++) e[q] = B[d0 + (uint32_t)q * 1024u + (uint32_t)t];
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (e[q] >> 16) e[q] = A[e[q] >> 16];
+#pragma unroll
+        for (int q = 0; q < 8; q++) N[d0 + (uint32_t)q * 1024u + (uint32_t)t] = e[q];
     }
-    for (uint32_t g = 0; g < G; g++) {
-        for (int q = 0; q < 4; q++) ((u32x4 *)(tails + (size_t)g * SY_W))[t * 4 + q] = ((const u32x4 *)s_f)[t * 4 + q];
-        if (g + 1 == G) break;
-        uint32_t w[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const u32x4 x = e[q];
-            const uint32_t b0 = (x.x >> 16) ? s_f[x.x >> 16] : (x.x & 255u), b1 = (x.y >> 16) ? s_f[x.y >> 16] : (x.y & 255u);
-            const uint32_t b2 = (x.z >> 16) ? s_f[x.z >> 16] : (x.z & 255u), b3 = (x.w >> 16) ? s_f[x.w >> 16] : (x.w & 255u);
-            w[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        }
-        if (g + 2 < G) {
-            const u32x4 *m = (const u32x4 *)(maps + ((size_t)(g + 1) * 2 + par[g + 1]) * SY_W) + (size_t)t * 16;
-#pragma unroll
-            for (int q = 0; q < 16; q++) e[q] = m[q];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; q++) { u32x4 v; v.x = w[4 * q]; v.y = w[4 * q + 1]; v.z = w[4 * q + 2]; v.w = w[4 * q + 3]; ((u32x4 *)s_f)[t * 4 + q] = v; }
-        __syncthreads();
+    if (t == 0) par_out[g] = pg ^ 1u;
+}
+// tails[g][d] = the final byte d positions in front of group g's first output byte: the scanned map of group g - 1 (what still is a
+// reference there points in front of the block: never used, pass A checked)
+__global__ __launch_bounds__(1024) void k_sy_front(const SyPlan *sy, const uint32_t *__restrict__ maps, const uint32_t *__restrict__ par, uint8_t *__restrict__ tails) {
+    if (!sy->go || sy->fail) return;
+    const uint32_t g = blockIdx.x;
+    if (g >= sy->groups) return;
+    const int t = threadIdx.x;
+    uint32_t *o = (uint32_t *)(tails + (size_t)g * SY_W);
+    if (g == 0u) { for (uint32_t i = t; i < SY_W / 4u; i += 1024u) o[i] = 0u; return; }
+    const u32x4 *m = (const u32x4 *)(maps + ((size_t)(g - 1u) * 2 + par[g - 1u]) * SY_W);
+    for (uint32_t i = t; i < SY_W / 4u; i += 1024u) {
+        const u32x4 x = m[i];
+        const uint32_t b0 = (x.x >> 16) ? 0u : (x.x & 255u), b1 = (x.y >> 16) ? 0u : (x.y & 255u), b2 = (x.z >> 16) ? 0u : (x.z & 255u), b3 = (x.w >> 16) ? 0u : (x.w & 255u);
+        o[i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     }
 }
 
@@ -475,8 +480,15 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     hb_prof_begin("k_sy_compose", s);
     hipLaunchKernelGGL(k_sy_compose, dim3(groups), dim3(1024), 0, s, un, list, sy, dst, S, maps, par);
     hb_prof_end(s);
-    hb_prof_begin("k_sy_chain", s);
-    hipLaunchKernelGGL(k_sy_chain, dim3(1), dim3(1024), 0, s, sy, maps, par, tails);
+    hb_prof_begin("k_sy_scan", s);
+    {
+        uint32_t *pin = par, *pout = par + SY_GROUPS;
+        for (uint32_t step = 1; step < groups; step <<= 1) {
+            hipLaunchKernelGGL(k_sy_scan, dim3(groups), dim3(1024), 0, s, sy, maps, pin, pout, step);
+            uint32_t *x = pin; pin = pout; pout = x;
+        }
+        hipLaunchKernelGGL(k_sy_front, dim3(groups), dim3(1024), 0, s, sy, maps, pin, tails);
+    }
     hb_prof_end(s);
     hb_prof_begin("k_sy_tails", s);
     hipLaunchKernelGGL(k_sy_tails, dim3(groups), dim3(1024), 0, s, un, list, sy, dst, S, tails);
