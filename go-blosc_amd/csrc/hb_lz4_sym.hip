@@ -8,7 +8,7 @@
 // ever named).  Copies copy references like values, so after one pass every output byte is either a value or a reference into the
 // 65535 bytes in front of its region -- chains of matches inside the region are flattened by the decode itself.
 //
-//   units   k_sy_units / k_sy_compact: one unit per region; a region with more than 1 MiB of output is cut into 8 at tokens the
+//   units   k_sy_units / k_sy_compact: one unit per region (two light neighbours share one); a region with more than 256 KiB of output is cut into 8 at tokens the
 //           discovery has on record (one wavefront copying 14 MiB of KiB-long matches is what everybody else would wait for).
 //   pass A  k_sy_decode    one wavefront per unit (the unit decoder of hb_sym_decode.h): tokens 64 at a time, one per lane; the last
 //                          4 KiB of output live in LDS, matches into it run LDS to LDS in dependency rounds, older sources are
@@ -31,7 +31,7 @@
 #define SY_W        65536u        // entries of a tail map / bytes of a tail image (index = distance 1..65535; entry 0 unused)
 #define SY_GROUPS   256u          // groups of units in pass B (128: k_sy_compose 1.9 ms, 256: 1.05, 512: 1.0 but the scan over the groups 0.4)
 #define SY_SUB      8u            // a region with more than SY_HEAVY bytes of output is decoded in this many parts
-#define SY_HEAVY    (1u << 20)
+#define SY_HEAVY    (256u << 10)  // (1 MiB until regions went down to 8 KiB: a short frame's 100:1 plane then sat in a few 800 KiB units -- 4 MiB frame 2.9 -> 1.8 ms)
 #define SY_MAXUNITS (RG_MAXREG * SY_SUB)
 #define SY_PIECE    (256u << 10)  // bytes of a region one workgroup resolves at a time (k_sy_resolve)
 #define SY_ROUNDS   3             // launches of pass A; the last one copies everything inline
