@@ -104,6 +104,39 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             // whole, and a pattern in the data itself costs what a stray start costs anyway.
             uint32_t found = RG_INVALID;                                  // token position, relative to `start`
             int tries = 4;
+            // The region BEGINS inside such a run (a match of 128 MiB has 526 KB of them: 64 regions): no token starts before the run
+            // ends.  Parsing "as if" from an FF byte would read the rest of the run as a literal length and land up to 255 bytes per
+            // FF further on -- a stray exit far behind the region, which the first belief round (a prefix maximum) would hand to
+            // every region in between, whose repair then walks region by region (measured, D-f64 as the reference writes it: 47 ms
+            // in k_rg_settle, then the single wavefront after all).  So: start behind the byte that ends the run, or -- when the
+            // whole region is FF -- record a region without a token (exit == entry: it says nothing).
+            {
+                bool inrun = RFL((uint32_t)src[start - 1u]) == 255u;
+                if (inrun) {
+                    const uint64_t i0 = (uint64_t)start + (uint32_t)lane;
+                    inrun = hb_ballot((uint32_t)lane < 16u && i0 < n_src && src[i0] != 255u) == 0ull;
+                }
+                if (inrun) {
+                    uint64_t e = bnext;                                   // the first byte that is not FF
+                    for (uint64_t at = start; at < bnext; at += 1024u) {
+                        const uint64_t idx = at + (uint64_t)lane * 16u;
+                        uint32_t fb = 16u;                                // my first byte that is not FF
+                        if (idx + 16u <= n_src) {
+                            const u32x4 v = ld16u(src + idx);
+                            const uint32_t w[4] = {~v.x, ~v.y, ~v.z, ~v.w};
+#pragma unroll
+                            for (int k = 3; k >= 0; k--) if (w[k]) fb = 4u * (uint32_t)k + ((uint32_t)__builtin_ctz(w[k]) >> 3);
+                        } else {
+                            for (uint32_t k = 0; k < 16u; k++) if (idx + k >= n_src || src[idx + k] != 255u) { fb = k; break; }
+                        }
+                        const unsigned long long m = hb_ballot(fb != 16u);
+                        if (m) { const int j = __builtin_ctzll(m); e = at + 16u * (uint64_t)j + __builtin_amdgcn_readlane(fb, j); break; }
+                    }
+                    start = (uint32_t)(e + 1u < bnext ? e + 1u : bnext);
+                    si = start;
+                    tries = 0;                                            // (no search below)
+                }
+            }
             for (uint64_t at = start; at < bnext && found == RG_INVALID && tries > 0; at += RG_PWIN - 512u) {
                 refill(at);
                 const uint32_t endo = wsh + wlen;                          // LDS offsets [wsh, endo) hold the window

@@ -315,3 +315,18 @@ def test_unit_order_of_the_unfused_decoder_covers_ragged_multi_pass_frames(hb, O
         assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, n, 0, 0) == n
         assert L.hb_last_result_flags() & 1
         assert np.array_equal(back, x), opts
+
+
+def test_long_length_extensions_do_not_derail_the_discovery(hb, O):
+    # a match of 100 MiB has 400 KB of FF bytes behind its offset: dozens of regions of the discovery BEGIN inside that run.  Parsed "as if
+    # a token started here" they used to report exits megabytes away, the first belief round took those for real, and the repair ran
+    # out of rounds (the frame then went to the single wavefront: 0.8 GB/s at 1 GiB).  D-f64 byte-shuffled (six of its eight planes
+    # compress 200:1) and the ramp (220:1 overall) as the reference writes them, 256 MiB each
+    L = hb.lib()
+    for name, x, ts in (("f64", O.synth(O.D_F64, (256 << 20) // 8), 8), ("ramp", O.synth(O.D_RAMP, (256 << 20) // 4), 4)):
+        f = O.compress_frame(x, shuffle=1, typesize=ts)
+        n = x.nbytes
+        back = np.zeros(n, np.uint8)
+        assert L.hb_decompress_frame(f.ctypes.data, f.size, back.ctypes.data, n, 0, 0) == n, name
+        assert L.hb_last_result_flags() & 1, f"{name}: the discovery gave up, the single wavefront decoded"
+        assert np.array_equal(back, x.view(np.uint8).reshape(-1)), name
