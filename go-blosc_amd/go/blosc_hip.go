@@ -222,7 +222,7 @@ func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 	// An LZ4 block is one serial chain.  With the restart index the device decodes it chunk-parallel; without one it
 	// first finds and verifies the token chain itself (payloads from 256 KiB: csrc/hb_lz4_region.hip) and then either
 	// rebuilds the index (frames this library wrote) or decodes symbolically (frames the CPU path wrote, hb_lz4_sym.hip):
-	// 101 / 242 GB/s device-resident at 1 GiB.  Below that size -- and for Snappy frames of other writers -- only ONE
+	// ~100 / ~240 GB/s device-resident at 1 GiB.  Below that size -- and for Snappy frames of other writers -- only ONE
 	// wavefront can work on it (~0.15-0.4 GB/s, measured), slower than the pure-Go decoder: those stay on the CPU
 	// unless the caller insists.
 	parallel := hasRestartIndex(data, h) || (Codec(h.VersionLZ) != Snappy && int(h.NBytesComp)-HeaderSize >= 256<<10)
