@@ -8,7 +8,7 @@
 // Both are resolved by GUESSING in parallel and then VERIFYING exactly; wrong guesses are repaired by iteration, and anything
 // that does not check out leaves the block to the single-wavefront decoder (k_dec_serial), so the result never depends on luck.
 //
-//   (1) Sequence boundaries (this file).  The stream is cut into <= 8192 regions at fixed byte positions b_r.  k_rg_parse: one
+//   (1) Sequence boundaries (this file).  The stream is cut into <= 16384 regions (>= 8 KiB) at fixed byte positions b_r.  k_rg_parse: one
 //       wavefront per region parses (window-parallel token parser, hb_lz4_region.h, no copies) to the first token at or after
 //       b_{r+1}, starting at a token it spotted by its long length extension (a run of FF bytes) or else at b_r AS IF a token
 //       started there; it keeps that exit, the output length, and a record {position, output so far} of its first 128 tokens and
