@@ -190,10 +190,15 @@ __global__ __launch_bounds__(256) void k_sy_big(const uint8_t *__restrict__ src,
     const uint32_t nb = sy->nbig;
     const int t = threadIdx.x;
     uint8_t *Sb = (uint8_t *)S;
+    // the 16 KiB pieces of ALL posted copies are dealt round-robin over the workgroups (piece c of copy i has the running number
+    // base_i + c): a frame of many 256 KiB matches -- 16 pieces each -- keeps the whole grid busy instead of 16 workgroups per copy
+    uint32_t base = 0;
     for (uint32_t i = 0; i < nb; i++) {
         const SyBig b = big[i];
         const uint32_t nch = (b.len + 16383u) >> 14;
-        for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        const uint32_t c0 = (blockIdx.x + gridDim.x - base % gridDim.x) % gridDim.x;
+        base += nch;
+        for (uint32_t c = c0; c < nch; c += gridDim.x) {
             const uint32_t x0 = c << 14, x1 = x0 + 16384u < b.len ? x0 + 16384u : b.len;
             if (b.kind == 0u) {                                          // literals from the stream (b.len >= SY_BIG: the last piece moves back)
                 u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
@@ -204,9 +209,12 @@ __global__ __launch_bounds__(256) void k_sy_big(const uint8_t *__restrict__ src,
                 }
             } else {                                                     // a match: the b.src bytes in front of b.dst, repeated
                 const uint32_t off = b.src, s0 = b.dst - off;
+                uint32_t m = (x0 + (uint32_t)t) % off;                  // x mod off, kept up by addition
+                const uint32_t step = 256u % off;
                 for (uint32_t x = x0 + (uint32_t)t; x < x1; x += 256u) {
-                    const uint32_t sp = s0 + x % off;
+                    const uint32_t sp = s0 + m;
                     if (sp >= b.O) { D[b.dst + x] = D[sp]; S[b.dst + x] = S[sp]; } else S[b.dst + x] = (uint16_t)(b.O - sp);
+                    m += step; if (m >= off) m -= off;
                 }
             }
         }
