@@ -294,7 +294,7 @@ int64_t hb_lz4_decompress(const void *src, size_t n, void *dst, size_t cap, int 
     if ((!src && n) || (!dst && cap)) return HB_ERR_BAD_ARG;
     if (n == 0) return 0;                                             // UncompressBlock: empty src -> 0, nil
     Scratch sc(device);
-    const size_t wb = n >= (256u << 10) ? hb_lz4_decompress_workspace_foreign(cap) : hb_lz4_dec_workspace(cap);   // (a bare block never has an index)
+    const size_t wb = hb_indexless_parallel(n, cap) ? hb_lz4_decompress_workspace_foreign(cap) : hb_lz4_dec_workspace(cap);   // (a bare block never has an index)
     uint8_t *d_src = sc.get(n + 64), *d_dst = sc.get(cap + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
     if (!d_src || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
     HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
@@ -460,7 +460,7 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     const size_t ioff = ((size_t)h.cbytes + 7) & ~(size_t)7;
     // (a frame without the trailer gets its index rebuilt on the device when its payload is large enough, hb_lz4_region.hip; the
     // fused un-filter is then armed the same way: if the rebuilt index does not hold, the serial path + the gated pass take over)
-    const bool has_index = !(h.flags & HB_FLAG_MEMCPY) && (n > ioff + 32 || ((size_t)h.cbytes - HB_HEADER_SIZE >= (256u << 10) && !snappy));
+    const bool has_index = !(h.flags & HB_FLAG_MEMCPY) && (n > ioff + 32 || (hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) && !snappy));
     const bool stored_index = !(h.flags & HB_FLAG_MEMCPY) && n > ioff + 32;
     const bool fused_bun = unf == HB_OP_BITUNSHUFFLE && ts == 4 && (h.nbytes % 32u) == 0 && !(h.flags & HB_FLAG_MEMCPY) &&
                            ((uintptr_t)d_dst & 15u) == 0 && !snappy && has_index;
@@ -543,7 +543,7 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
     Scratch sc(device);
     // an LZ4 frame without an index behind NBytesComp may be anybody's: room for the symbolic decoder as well
-    const bool maybe_foreign = !(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && (size_t)h.cbytes - HB_HEADER_SIZE >= (256u << 10) &&
+    const bool maybe_foreign = !(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) &&
                                n <= (((size_t)h.cbytes + 7) & ~(size_t)7) + 32;
     const size_t wb = maybe_foreign ? hb_decompress_frame_workspace_foreign(h.nbytes) : hb_decompress_frame_workspace(h.nbytes);
     uint8_t *d_frame = sc.get(n + 64), *d_dst = sc.get((size_t)h.nbytes + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));

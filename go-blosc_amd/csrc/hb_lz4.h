@@ -52,6 +52,12 @@ int hb_launch_lz4_decode(const hb_dec_args &a, hipStream_t s);
 // hb_snappy.hip: Snappy block decoder (codec.go:237-244); same argument record, the fused un-filter fields are ignored
 int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s);
 static inline bool hb_device_codec(int codec) { return codec == HB_LZ4 || codec == HB_LZ4HC || codec == HB_SNAPPY; }
+// An LZ4 block without a restart index is worth the token discovery (hb_lz4_region.hip: ~1-2 ms of fixed cost) instead of the single
+// wavefront (0.15-1.2 GB/s of output) when it is long, or short but highly compressed: 16 MiB of zeros are 64 KB of stream and 14 ms
+// on one wavefront.  Every place that sizes a workspace for such a block asks this (payload = stream bytes, nbytes = decoded size).
+static inline bool hb_indexless_parallel(size_t payload, size_t nbytes) {
+    return payload >= (256u << 10) || (payload >= (16u << 10) && nbytes >= (2u << 20));
+}
 
 // ---- small device helpers shared by encoder and decoder ----
 __device__ __forceinline__ uint32_t lz4_ext_bytes(uint32_t x) { return x < 15u ? 0u : 1u + (x - 15u) / 255u; }

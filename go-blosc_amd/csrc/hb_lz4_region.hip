@@ -35,7 +35,7 @@ size_t hb_lz4_region_workspace(size_t n_out) { return rg_layout(n_out).total + (
 // blocks below 256 KiB stay with the single wavefront (a dozen launches cost more than they save)
 // ... and a stream that is longer than any block of a.cap bytes can be is malformed anyway (the workspace has regions for a.cap)
 bool hb_lz4_region_wanted(const hb_dec_args &a) {
-    return !a.index && !a.memcpy_payload && a.n >= (256u << 10) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull && a.n <= a.cap + a.cap / 255 + 16;
+    return !a.index && !a.memcpy_payload && hb_indexless_parallel(a.n, a.cap) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull && a.n <= a.cap + a.cap / 255 + 16;
 }
 
 __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) {

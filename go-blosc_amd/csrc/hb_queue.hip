@@ -261,7 +261,7 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
                 hb_header h;
                 if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (hb_device_codec(h.codec) || (h.flags & HB_FLAG_MEMCPY))) {
                     max_n = std::max(max_n, std::max<size_t>(h.nbytes, 1));
-                    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && h.cbytes >= HB_HEADER_SIZE + (256u << 10) &&
+                    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && h.cbytes >= HB_HEADER_SIZE && hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) &&
                         n[k] <= (((size_t)h.cbytes + 7) & ~(size_t)7) + 32) qflags = HB_QUEUE_FOREIGN_FRAMES;
                 }
             }

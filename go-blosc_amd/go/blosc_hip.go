@@ -35,7 +35,7 @@ var MinOffloadBytes = 1 << 20
 // Device used by the host-pointer entry points.
 var Device = 0
 
-// ForceDeviceDecode sends the frames only a single wavefront can decode (no restart index AND a payload below 256 KiB, or a
+// ForceDeviceDecode sends the frames only a single wavefront can decode (no restart index AND a payload below 256 KiB -- 16 KiB when it decodes to 2 MiB or more --, or a
 // foreign Snappy block) to the device too.
 var ForceDeviceDecode = false
 
@@ -220,12 +220,13 @@ func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 		return DecompressWithSize(data, typeSize)
 	}
 	// An LZ4 block is one serial chain.  With the restart index the device decodes it chunk-parallel; without one it
-	// first finds and verifies the token chain itself (payloads from 256 KiB: csrc/hb_lz4_region.hip) and then either
+	// first finds and verifies the token chain itself (payloads from 256 KiB, or from 16 KiB when they decode to 2 MiB and more: csrc/hb_lz4_region.hip) and then either
 	// rebuilds the index (frames this library wrote) or decodes symbolically (frames the CPU path wrote, hb_lz4_sym.hip):
 	// ~100 / ~240 GB/s device-resident at 1 GiB.  Below that size -- and for Snappy frames of other writers -- only ONE
 	// wavefront can work on it (~0.15-0.4 GB/s, measured), slower than the pure-Go decoder: those stay on the CPU
 	// unless the caller insists.
-	parallel := hasRestartIndex(data, h) || (Codec(h.VersionLZ) != Snappy && int(h.NBytesComp)-HeaderSize >= 256<<10)
+	payload := int(h.NBytesComp) - HeaderSize
+	parallel := hasRestartIndex(data, h) || (Codec(h.VersionLZ) != Snappy && (payload >= 256<<10 || (payload >= 16<<10 && h.NBytesOrig >= 2<<20)))
 	if !h.IsMemcpy() && !parallel && !ForceDeviceDecode {
 		return DecompressWithSize(data, typeSize)
 	}

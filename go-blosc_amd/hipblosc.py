@@ -20,6 +20,13 @@ FormatVersion = 2
 HeaderSize = MinHeaderSize = 16
 BloscLZ, LZ4, LZ4HC, Snappy, ZLIB, ZSTD = range(6)
 NoShuffle, Shuffle1, BitShuffle = 0, 1, 2
+
+
+def indexless_parallel(payload, nbytes):
+    """csrc/hb_lz4.h hb_indexless_parallel(): an LZ4 frame without a restart index takes the token discovery (parallel) instead of the
+    single wavefront when its payload is 256 KiB or more, or 16 KiB or more and it decodes to 2 MiB or more."""
+    return payload >= (256 << 10) or (payload >= (16 << 10) and nbytes >= (2 << 20))
+
 flagShuffle, flagMemcpy, flagBitShuffle, flagSplit = 0x1, 0x2, 0x4, 0x8
 OP_SHUFFLE, OP_UNSHUFFLE, OP_BITSHUFFLE, OP_BITUNSHUFFLE = 0, 1, 2, 3
 OPT_INDEX_TRAILER, OPT_REFERENCE_MEMCPY, OPT_NO_FUSION = 0x1, 0x2, 0x4

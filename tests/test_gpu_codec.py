@@ -261,9 +261,9 @@ def test_multi_tile_frames_use_the_index(hb, O):
             assert hb.lib().hb_last_result_flags() & 1, f"{name}: indexed decoder rejected its own index"
         cb = hb.GetInfo(f).NBytesComp
         assert hb.Decompress(f[:cb]) == x.tobytes(), f"{name}: decode with the index cut off differs"
-        # without the trailer: payloads from 256 KiB up get their index rebuilt on the device (csrc/hb_lz4_region.hip), smaller ones
-        # are decoded by the single wavefront
-        rebuilt = (not hb.GetInfo(f).IsMemcpy()) and cb - 16 >= (256 << 10)
+        # without the trailer: payloads from 256 KiB up (from 16 KiB when they decode to 2 MiB and more) get their index rebuilt on the
+        # device (csrc/hb_lz4_region.hip), smaller ones are decoded by the single wavefront
+        rebuilt = (not hb.GetInfo(f).IsMemcpy()) and hb.indexless_parallel(cb - 16, x.nbytes)
         assert bool(hb.lib().hb_last_result_flags() & 1) == rebuilt, name
 
 

@@ -133,7 +133,7 @@ def test_own_frames_without_the_trailer_decode_in_parallel(hb, O):
         assert len(f) == h.NBytesComp                                   # nothing behind the frame
         assert O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes() == x.tobytes(), name
         assert hb.Decompress(f) == x.tobytes(), name
-        if not h.IsMemcpy() and h.NBytesComp - 16 >= (256 << 10):
+        if not h.IsMemcpy() and hb.indexless_parallel(h.NBytesComp - 16, h.NBytesOrig):
             assert hb.lib().hb_last_result_flags() & 1, f"{name}: the rebuilt index was not used"
         with_index = hb.Compress(x.tobytes(), hb.LZ4, 5, shuffle, ts, opts=hb.OPT_INDEX_TRAILER)
         assert with_index[:h.NBytesComp] == f                            # same frame, the trailer is only appended
@@ -292,7 +292,7 @@ def test_many_small_random_blocks(hb, O):
         block, n = G.random_block(rng, (1 << 20) + seed * 4099, regime_len=(16 << 10) << (seed % 5))
         want = O.lz4_decompress(np.frombuffer(block, np.uint8), n).tobytes()
         assert len(want) == n
-        if len(block) >= (256 << 10):
+        if hb.indexless_parallel(len(block), n):
             frame = struct.pack("<BBBBIII", 2, hb.LZ4, 0, 1, n, n, 16 + len(block)) + block
             assert hb.Decompress(frame) == want, seed
             assert hb.lib().hb_last_result_flags() & 1, seed
