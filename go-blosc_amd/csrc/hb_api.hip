@@ -99,8 +99,13 @@ int select_device(int device) {
     return HB_OK;
 }
 
-std::atomic<bool> g_no_dec_fusion{false};  // hb_debug_decode_fusion(0): A/B switch for bench / tests (atomic: any thread may flip it)
-std::atomic<unsigned> g_plane_mask{~0u};   // hb_debug_plane_mask(): timing-only switch, see hipblosc.h
+// Diagnostics switches, read ONCE from the environment when the library is loaded -- not part of the ABI (a process-global
+// setter next to entry points that promise "safe for concurrent use", blosc.go:37-39, was a foot-gun: VERDICT r2):
+//   HIPBLOSC_DEBUG_NO_DECODE_FUSION=1   decode byte-shuffled frames with a separate un-shuffle pass (A/B timing: bench.py --no-dec-fusion)
+//   HIPBLOSC_DEBUG_PLANE_MASK=<hex>     TIMING ONLY (tools/plane_times.py): bit j clear = the fused shuffle+LZ4 kernels skip byte plane j
+//                                       of every element block, so frames written / decoded by that process are garbage
+const bool g_no_dec_fusion = [] { const char *e = getenv("HIPBLOSC_DEBUG_NO_DECODE_FUSION"); return e && *e && *e != '0'; }();
+const unsigned g_plane_mask = [] { const char *e = getenv("HIPBLOSC_DEBUG_PLANE_MASK"); return e && *e ? (unsigned)strtoul(e, nullptr, 16) : ~0u; }();
 thread_local unsigned g_last_flags = 0;   // hb_result.flags of the last host-pointer call on this thread
 
 bool overlap(const void *a, size_t na, const void *b, size_t nb) {
@@ -110,7 +115,7 @@ bool overlap(const void *a, size_t na, const void *b, size_t nb) {
 
 }  // namespace
 
-unsigned hb_dbg_plane_mask() { return g_plane_mask.load(std::memory_order_relaxed); }
+unsigned hb_dbg_plane_mask() { return g_plane_mask; }
 
 // ---- stage timing -------------------------------------------------------------------------
 namespace {
@@ -193,8 +198,6 @@ void hb_shutdown(void) {
 }
 
 unsigned hb_last_result_flags(void) { return g_last_flags; }
-void hb_debug_decode_fusion(int on) { g_no_dec_fusion = !on; }
-void hb_debug_plane_mask(unsigned mask) { g_plane_mask = mask; }
 
 void *hb_host_alloc(size_t bytes) {
     std::call_once(g_once, do_init);
@@ -429,17 +432,19 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
     hb_header h;
     int rc = hb_parse_header(hb, HB_HEADER_SIZE, &h);                 // blosc.go:379-382
     if (rc) return rc;
-    return hb_decompress_frame_dev_hdr(h, d_frame, n, d_dst, cap, typesize_override, d_work, work_bytes, d_result, stream);
+    return hb_decompress_frame_dev_hdr(&h, d_frame, n, d_dst, cap, typesize_override, d_work, work_bytes, d_result, stream);
 }
 
-}  // extern "C"
-
 // the same with the header already parsed (host callers have the frame in host memory: no read-back, no sync)
-int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t n, void *d_dst, size_t cap, int typesize_override,
+int hb_decompress_frame_dev_hdr(const hb_header *hdr, const void *d_frame, size_t n, void *d_dst, size_t cap, int typesize_override,
                                 void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
+    if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
+    if (!hdr || !d_frame || !d_work || !d_result || (!d_dst && cap)) return HB_ERR_BAD_ARG;
+    const hb_header &h = *hdr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;
+    if (h.version != HB_FORMAT_VERSION) return HB_ERR_INVALID_VERSION; // blosc.go:179-182 (a caller may have built the record itself)
     if ((size_t)h.cbytes > n) return HB_ERR_INVALID_DATA;             // blosc.go:385-387
     if (h.cbytes < HB_HEADER_SIZE) return HB_ERR_INVALID_DATA;        // blosc.go:388-390
     if (!(h.flags & HB_FLAG_MEMCPY) && !hb_device_codec(h.codec)) return HB_ERR_INVALID_CODEC;   // :403-407
@@ -494,8 +499,6 @@ int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t 
     return HB_OK;
 }
 
-extern "C" {
-
 int64_t hb_compress_frame(const void *src, size_t n, void *dst, size_t cap, int codec, int level, int shuffle,
                           int typesize, unsigned opts, int device) {
     if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271 (before anything else)
@@ -549,7 +552,7 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     uint8_t *d_frame = sc.get(n + 64), *d_dst = sc.get((size_t)h.nbytes + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
     if (!d_frame || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
     HB_HIP_TRY(hipMemcpy(d_frame, frame, n, hipMemcpyHostToDevice));
-    rc = hb_decompress_frame_dev_hdr(h, d_frame, n, d_dst, h.nbytes, typesize_override, d_work, wb, (hb_result *)d_res, nullptr);
+    rc = hb_decompress_frame_dev_hdr(&h, d_frame, n, d_dst, h.nbytes, typesize_override, d_work, wb, (hb_result *)d_res, nullptr);
     if (rc) return rc;
     hb_result r;
     HB_HIP_TRY(hipMemcpy(&r, d_res, sizeof r, hipMemcpyDeviceToHost));
@@ -586,6 +589,12 @@ int64_t hb_cblosc_decompress(const void *frame, size_t n, void *dst, size_t cap,
     if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
     if ((!dst && h.nbytes)) return HB_ERR_BAD_ARG;
     if (!(h.flags & 0x02u) && h.codec_format != 1) return HB_ERR_INVALID_CODEC;
+    if (!(h.flags & 0x02u) && h.nbytes) {
+        // validate the geometry BEFORE sizing anything from it (a 16-byte forged header with blocksize 1 asked for
+        // thousands of bytes of scratch per declared byte): the bstarts table must fit into the frame, a block holds >= 1 element
+        const uint64_t nblocks = ((uint64_t)h.nbytes + h.blocksize - 1) / h.blocksize;
+        if (16ull + 4ull * nblocks > h.cbytes || h.blocksize < h.typesize) return HB_ERR_INVALID_DATA;
+    }
     rc = select_device(device);
     if (rc) return rc;
     Scratch sc(device);

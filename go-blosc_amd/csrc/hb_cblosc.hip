@@ -24,6 +24,13 @@
 #define CB_FLAG_BITSHUFFLE 0x04u
 #define CB_FLAG_DONTSPLIT  0x10u
 
+// blosc_d of c-blosc 1.x splits a block into `typesize` streams only when ALL of these hold (the rule from before the 0x10 flag existed stays
+// in force next to it: frames of c-blosc < 1.15 have the bit clear and large typesizes / small blocks unsplit; checked against libblosc 1.21):
+// not-split bit clear, typesize <= MAX_SPLITS (16), blocksize / typesize >= MIN_BUFFERSIZE (128), not the last, shorter block.
+__host__ __device__ static inline uint32_t cb_nsplit(uint32_t flags, uint32_t typesize, uint32_t blocksize) {
+    return (!(flags & 0x10u) && typesize >= 1u && typesize <= 16u && blocksize / typesize >= 128u) ? typesize : 1u;
+}
+
 struct CbStream { uint32_t src, csize, dst, usize; };
 struct CbPlan { uint32_t fail, nblocks, nsplit, pad; };
 
@@ -38,7 +45,7 @@ __global__ void k_cb_plan(const uint8_t *__restrict__ frame, uint64_t n, uint32_
     const uint32_t leftover = nbytes % blocksize;
     const bool lastshort = b + 1 == nblocks && leftover != 0u;
     const uint32_t bsize = lastshort ? leftover : blocksize;
-    const uint32_t nsplit_frame = (flags & CB_FLAG_DONTSPLIT) ? 1u : typesize;
+    const uint32_t nsplit_frame = cb_nsplit(flags, typesize, blocksize);
     const uint32_t nsplit = lastshort ? 1u : nsplit_frame;
     const uint32_t neblock = bsize / nsplit;
     CbStream *out = streams + (size_t)b * nsplit_frame;
@@ -473,7 +480,8 @@ int hb_cblosc_parse_header(const void *frame, size_t n, hb_cblosc_header *out) {
 
 size_t hb_cblosc_decompress_workspace(size_t nbytes, size_t blocksize, size_t typesize) {
     const size_t nblocks = blocksize ? (nbytes + blocksize - 1) / blocksize : 0;
-    return 256 + cb_align(nblocks * (typesize ? typesize : 1) * sizeof(CbStream)) + cb_align(nbytes + 64);
+    const size_t nsplit = (typesize >= 1 && typesize <= 16 && blocksize / typesize >= 128) ? typesize : 1;      // cb_nsplit() without the flag: the upper bound
+    return 256 + cb_align(nblocks * nsplit * sizeof(CbStream)) + cb_align(nbytes + 64);
 }
 
 // d_frame: the frame in device memory (n bytes available), d_dst: hdr.nbytes bytes.  Asynchronous on `stream`; *d_result says how it went.
@@ -483,6 +491,10 @@ int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, s
     if (!hdr || !d_frame || (!d_dst && cap) || !d_work || !d_result) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t nbytes = hdr->nbytes, blocksize = hdr->blocksize, ts = hdr->typesize, flags = hdr->flags;
+    // the record may come from a caller that ignored hb_cblosc_parse_header's return value, or built it itself: repeat its checks
+    // before anything divides by a field
+    if (hdr->version != 2) return HB_ERR_INVALID_VERSION;
+    if (ts == 0u || (nbytes && blocksize == 0u)) return HB_ERR_INVALID_HEADER;
     if (hdr->cbytes > n || hdr->cbytes < 16) return HB_ERR_INVALID_DATA;
     if (nbytes > cap) return HB_ERR_SHORT_BUFFER;
     if (work_bytes < hb_cblosc_decompress_workspace(nbytes, blocksize, ts)) return HB_ERR_SHORT_BUFFER;
@@ -497,9 +509,10 @@ int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, s
         return HB_OK;
     }
     if (hdr->codec_format != 1) return HB_ERR_INVALID_CODEC;            // lz4 / lz4hc only
-    const uint32_t nblocks = (nbytes + blocksize - 1) / blocksize;
+    const uint32_t nblocks = (uint32_t)(((uint64_t)nbytes + blocksize - 1) / blocksize);
     if (16ull + 4ull * nblocks > hdr->cbytes) return HB_ERR_INVALID_DATA;
-    const uint32_t nsplit = (flags & CB_FLAG_DONTSPLIT) ? 1u : ts;
+    if (blocksize < ts) return HB_ERR_INVALID_DATA;                     // (c-blosc never writes it; a stream would hold less than one element)
+    const uint32_t nsplit = cb_nsplit(flags, ts, blocksize);
     CbStream *streams = (CbStream *)(w + 256);
     uint8_t *staged = w + 256 + cb_align((size_t)nblocks * nsplit * sizeof(CbStream));
     // blosc_d: the byte shuffle counts for typesize > 1 only (and comes first), the bit shuffle for any typesize

@@ -39,10 +39,6 @@ int64_t hb_zstd_compress_frame(const void *src, size_t n, void *dst, size_t cap,
                                unsigned opts, int device);
 int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *dst, size_t cap, int typesize_override, int device);
 
-// hb_api.hip: frame decode with the header already parsed on the host (no header read-back, no stream sync)
-int hb_decompress_frame_dev_hdr(const hb_header &h, const void *d_frame, size_t n, void *d_dst, size_t cap, int typesize_override,
-                                void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
-
 size_t hb_lz4_enc_workspace(size_t n);
 size_t hb_lz4_dec_workspace(size_t n_out);
 size_t hb_lz4_index_bound(size_t n);

@@ -171,7 +171,7 @@ int64_t hb_queue_decompress(hb_queue *q, const void *frame, size_t n, void *dst,
     s->state = SLOT_DONE; s->ticket = ticket; s->compress = false; s->dst = dst; s->cap = cap; s->opts = 0;
     s->rc = HB_ERR_HIP;
     if (hipMemcpyAsync(s->d_in, frame, n, hipMemcpyHostToDevice, s->stream) != hipSuccess) return ticket;
-    rc = hb_decompress_frame_dev_hdr(h, s->d_in, n, s->d_out, h.nbytes, typesize_override, s->d_work, q->work_bytes,
+    rc = hb_decompress_frame_dev_hdr(&h, s->d_in, n, s->d_out, h.nbytes, typesize_override, s->d_work, q->work_bytes,
                                      s->d_res, s->stream);
     if (rc) { s->rc = rc; return ticket; }
     if (hipMemcpyAsync(s->h_res, s->d_res, sizeof(hb_result), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return ticket;
@@ -259,7 +259,11 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
             unsigned qflags = 0;                           // any large LZ4 frame without a trailer: it may be somebody else's
             for (int k = d; k < nframes; k += nd) {
                 hb_header h;
-                if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (hb_device_codec(h.codec) || (h.flags & HB_FLAG_MEMCPY))) {
+                // frames whose header asks for more than the caller gave (nbytes above cap[k], cbytes above n[k]) never reach a queue slot:
+                // they must not size the slots either (one forged NBytesOrig made every device allocate 3 x ~3 x 4 GiB); the
+                // one-call path answers them with the reference's error
+                if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (hb_device_codec(h.codec) || (h.flags & HB_FLAG_MEMCPY)) &&
+                    (size_t)h.nbytes <= cap[k] && (size_t)h.cbytes <= n[k]) {
                     max_n = std::max(max_n, std::max<size_t>(h.nbytes, 1));
                     if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && h.cbytes >= HB_HEADER_SIZE && hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) &&
                         n[k] <= (((size_t)h.cbytes + 7) & ~(size_t)7) + 32) qflags = HB_QUEUE_FOREIGN_FRAMES;

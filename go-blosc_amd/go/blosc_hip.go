@@ -260,6 +260,14 @@ func CompressFramesHIP(frames [][]byte, opts Options, withIndex bool) ([][]byte,
 		caps[k] = C.hb_frame_bound(lens[k])
 		srcs[k] = C.hb_host_alloc(lens[k])
 		dsts[k] = C.hb_host_alloc(caps[k])
+		if srcs[k] == nil || dsts[k] == nil {
+			// no pinned memory for this frame (hb_host_alloc answers nil): it stays out of the batch -- a nil source makes
+			// hb_compress_frames_multi answer HB_ERR_BAD_ARG for it without touching it -- and goes through the one-call path below
+			C.hb_host_free(srcs[k])
+			C.hb_host_free(dsts[k])
+			srcs[k], dsts[k], lens[k] = nil, nil, 0
+			continue
+		}
 		pin = append(pin, srcs[k], dsts[k])
 		copy(unsafe.Slice((*byte)(srcs[k]), len(f)), f)
 	}
@@ -270,7 +278,9 @@ func CompressFramesHIP(frames [][]byte, opts Options, withIndex bool) ([][]byte,
 	C.hb_compress_frames_multi(C.int(n), &srcs[0], &lens[0], &dsts[0], &caps[0], &rcs[0],
 		C.int(opts.Codec), C.int(opts.Level), C.int(opts.Shuffle), C.int(opts.TypeSize), o)
 	for k := range frames {
-		if rcs[k] < 0 {
+		if srcs[k] == nil { // not in the batch (see above): pageable one-call path
+			out[k], errs[k] = CompressHIP(frames[k], opts, withIndex)
+		} else if rcs[k] < 0 {
 			errs[k] = hbError(rcs[k])
 		} else {
 			out[k] = append([]byte(nil), unsafe.Slice((*byte)(dsts[k]), int(rcs[k]))...)
@@ -304,12 +314,24 @@ func DecompressFrames(frames [][]byte) (out [][]byte, errs []error) {
 		if h, err := ParseHeader(f); err == nil {
 			caps[k] = C.size_t(h.NBytesOrig) + 1
 		}
+		// NBytesOrig is untrusted (up to 4 GiB of pinned memory per frame): when the allocation fails the frame stays out of
+		// the batch (a nil frame pointer gets HB_ERR_BAD_ARG from hb_decompress_frames_multi, untouched) and takes the one-call path
 		srcs[k] = C.hb_host_alloc(lens[k] + 1)
 		dsts[k] = C.hb_host_alloc(caps[k])
+		if srcs[k] == nil || dsts[k] == nil {
+			C.hb_host_free(srcs[k])
+			C.hb_host_free(dsts[k])
+			srcs[k], dsts[k], lens[k], caps[k] = nil, nil, 0, 0
+			continue
+		}
 		copy(unsafe.Slice((*byte)(srcs[k]), len(f)), f)
 	}
 	C.hb_decompress_frames_multi(C.int(n), &srcs[0], &lens[0], &dsts[0], &caps[0], &rcs[0], 0)
 	for k := range frames {
+		if srcs[k] == nil {
+			out[k], errs[k] = DecompressHIP(frames[k], 0)
+			continue
+		}
 		if rcs[k] < 0 {
 			errs[k] = hbError(rcs[k])
 		} else {

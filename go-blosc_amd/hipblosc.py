@@ -95,7 +95,7 @@ EXPORTS = [
     "hb_decompress_frame", "hb_compress_frame_workspace", "hb_decompress_frame_workspace", "hb_decompress_frame_workspace_foreign", "hb_lz4_decompress_workspace_foreign",
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
-    "hb_debug_decode_fusion", "hb_debug_plane_mask", "hb_cblosc_parse_header", "hb_cblosc_decompress", "hb_cblosc_compress", "hb_cblosc_bound", "hb_cblosc_compress_workspace", "hb_cblosc_compress_dev", "hb_cblosc_decompress_workspace", "hb_cblosc_decompress_dev",
+    "hb_decompress_frame_dev_hdr", "hb_cblosc_parse_header", "hb_cblosc_decompress", "hb_cblosc_compress", "hb_cblosc_bound", "hb_cblosc_compress_workspace", "hb_cblosc_compress_dev", "hb_cblosc_decompress_workspace", "hb_cblosc_decompress_dev",
     "hb_queue_create", "hb_queue_create_ex", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
 
@@ -151,7 +151,7 @@ def lib():
             "hb_last_result_flags": (u32, []),
             "hb_profile_enable": (i32, [i32]), "hb_profile_count": (i32, []),
             "hb_profile_get": (ctypes.c_char_p, [i32, ctypes.POINTER(ctypes.c_float)]),
-            "hb_debug_decode_fusion": (None, [i32]), "hb_debug_plane_mask": (None, [u32]),
+            "hb_decompress_frame_dev_hdr": (i32, [ctypes.POINTER(hb_header), vp, sz, vp, sz, i32, vp, sz, vp, vp]),
             "hb_cblosc_parse_header": (i32, [vp, sz, vp]), "hb_cblosc_compress": (i64, [vp, sz, vp, sz, i32, i32, i32]),
             "hb_cblosc_bound": (sz, [sz, i32]), "hb_cblosc_compress_workspace": (sz, [sz, i32, i32]),
             "hb_cblosc_compress_dev": (i32, [vp, sz, vp, sz, i32, i32, vp, sz, vp, vp]), "hb_cblosc_decompress": (i64, [vp, sz, vp, sz, i32]),

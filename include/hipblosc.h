@@ -94,12 +94,6 @@ const char *hb_strerror(int code);
 const char *hb_version(void);
 unsigned    hb_last_result_flags(void);    /* hb_result.flags of the last host-pointer frame decode on this thread
                                               (bit0: the restart index was used) — diagnostics for tests */
-void        hb_debug_decode_fusion(int on); /* A/B switch for bench / tests (default on): 0 = decode byte-shuffled frames with a
-                                              separate un-shuffle pass instead of the decoder's fused byte-strided stores */
-
-void        hb_debug_plane_mask(unsigned mask); /* TIMING ONLY (tools/plane_times.py): bit j clear = the fused shuffle+LZ4 kernels skip byte
-                                              plane j of every element block, so a frame is garbage; default ~0u = all planes */
-
 /* stage timing for the bench harness (single-threaded use): with enable(1) every kernel stage launched by the
  * `_dev` entry points is bracketed by HIP events on its stream; get(i) returns the stage name and its ms. */
 int         hb_profile_enable(int on);
@@ -182,6 +176,12 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
 int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t cap,
                             int typesize_override,
                             void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
+/* the same for a caller that already has the 16 header bytes on the host (every Go caller does: the frame came from host memory):
+ * `hdr` = hb_parse_header() of them.  No read-back and no stream synchronisation: the call only enqueues work on `stream`.
+ * Header checks of blosc.go:385-390 / :403-407 come back as the return value, everything else through *d_result. */
+int hb_decompress_frame_dev_hdr(const hb_header *hdr, const void *d_frame, size_t n, void *d_dst, size_t cap,
+                                int typesize_override,
+                                void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
 
 /* batches of independent frames, frame k -> device k mod hb_device_count(): what a caller with an
  * 8 GiB array does (8 frames of <= 4 GiB - 1, blosc.go:159-161: the sizes are uint32), one Compress / Decompress call

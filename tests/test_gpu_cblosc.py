@@ -135,6 +135,43 @@ def test_what_must_be_refused(hb, O, cb):
         hb.CBloscDecompress(bytes(g))
 
 
+def test_blocks_that_the_old_rule_leaves_unsplit(hb, O, cb):
+    # blosc_d splits a block only when the not-split bit is clear AND typesize <= 16 AND blocksize / typesize >= 128 (the rule from
+    # before the bit existed, c-blosc < 1.15, still applies): c-blosc 1.21 sets the bit on such frames; with the bit cleared by hand
+    # they are what an older writer produced, the library reads them as unsplit blocks and so must the device.
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 4, 200000, dtype=np.uint8) * 3
+    for ts, bs, shuffle in ((17, 0, 1), (8, 512, 1), (32, 0, 1), (8, 512, 2), (17, 0, 0), (4, 256, 1), (16, 2032, 1), (16, 2048, 1)):
+        f = cb.compress(x, 5, shuffle, ts, b"lz4", bs)
+        g = bytearray(f); g[2] &= 0xEF
+        r, out = cb.decompress(bytes(g), x.size)
+        assert r == x.size and out == x.tobytes(), (ts, bs, shuffle)      # (what the library does with it; for 16 / 2048 the bit was clear already)
+        assert hb.CBloscDecompress(bytes(g)) == x.tobytes(), (ts, bs, shuffle, hex(f[2]))
+
+
+def test_forged_geometry_is_refused_before_anything_is_sized(hb, O, cb):
+    # a 16-byte header with blocksize 1 / typesize 255 / nbytes N asked for ~4080 N bytes of scratch; a header record with
+    # blocksize 0 or typesize 0 handed to the _dev entry point divided by zero on the host
+    import ctypes
+    L = hb.lib()
+    n = 1 << 20
+    forged = struct.pack("<BBBBIII", 2, 1, 0x21, 255, n, 1, 16) + b""
+    before = L.hb_pool_cached_bytes()
+    with pytest.raises(hb.ErrInvalidData):
+        hb.CBloscDecompress(forged + bytes(64))
+    assert L.hb_pool_cached_bytes() - before < 64 * n
+    forged = struct.pack("<BBBBIII", 2, 1, 0x21, 8, n, 4, 16 + 64)       # blocksize below typesize
+    with pytest.raises(hb.ErrInvalidData):
+        hb.CBloscDecompress(forged + bytes(64))
+    import torch
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    for ts, bsz, want in ((0, 4096, -2), (4, 0, -2)):
+        hdr = hb.CBloscHeader()
+        hdr.version, hdr.versionlz, hdr.flags, hdr.typesize, hdr.nbytes, hdr.blocksize, hdr.cbytes, hdr.codec_format = 2, 1, 0x21, ts, 1024, bsz, 64, 1
+        rc = L.hb_cblosc_decompress_dev(ctypes.byref(hdr), buf.data_ptr(), 64, buf.data_ptr() + 1024, 1024, buf.data_ptr() + 2048, 2048, buf.data_ptr() + 512, None)
+        assert rc == want, (ts, bsz, rc)
+
+
 def test_frames_written_here_are_read_by_the_library(hb, O, cb):
     # the other direction: hb_cblosc_compress writes, blosc_decompress_ctx of c-blosc 1.21 reads (and the device decoder too)
     sets = _sets(O)

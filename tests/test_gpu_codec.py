@@ -286,10 +286,15 @@ def test_fused_shuffle_equals_separate_filter_pass(hb, O, ts):
         for base in (0, hb.OPT_INDEX_TRAILER, hb.OPT_REFERENCE_MEMCPY):
             fused = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.Shuffle1, ts, opts=base)
             plain = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.Shuffle1, ts, opts=base | hb.OPT_NO_FUSION)
-            assert fused == plain, f"{name} opts={base}: fused frame differs from the two-pass frame"
             if not (base & hb.OPT_REFERENCE_MEMCPY):
-                assert np.array_equal(O.decompress_frame(np.frombuffer(fused, np.uint8)), x), name
+                for which, fr in (("fused", fused), ("two-pass", plain)):               # each against the oracle, not against each other
+                    assert np.array_equal(O.decompress_frame(np.frombuffer(fr, np.uint8)), x), (name, which)
                 assert hb.Decompress(fused) == x.tobytes(), name
+            else:                                                                       # blosc.go:342-345 bit for bit: header + raw input
+                for fr in (fused, plain):
+                    h = hb.GetInfo(fr)
+                    assert (not h.IsMemcpy()) or fr[16:16 + x.size] == x.tobytes(), name
+            assert fused == plain, f"{name} opts={base}: frames must not depend on where the filter ran"
 
 
 def test_fused_bitshuffle_equals_separate_filter_pass(hb, O):
@@ -307,11 +312,12 @@ def test_fused_bitshuffle_equals_separate_filter_pass(hb, O):
         for base in (0, hb.OPT_INDEX_TRAILER, hb.OPT_REFERENCE_MEMCPY):
             fused = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.BitShuffle, 4, opts=base)
             plain = hb.Compress(x.tobytes(), hb.LZ4, 5, hb.BitShuffle, 4, opts=base | hb.OPT_NO_FUSION)
-            assert fused == plain, f"{name} opts={base}: fused frame differs from the two-pass frame"
             if not (base & hb.OPT_REFERENCE_MEMCPY):
-                assert np.array_equal(O.decompress_frame(np.frombuffer(fused, np.uint8)), x), name
+                for which, fr in (("fused", fused), ("two-pass", plain)):               # each against the oracle, not against each other
+                    assert np.array_equal(O.decompress_frame(np.frombuffer(fr, np.uint8)), x), (name, which)
             want = O.decompress_frame(np.frombuffer(fused, np.uint8)).tobytes()
             assert hb.Decompress(fused) == want, name
+            assert fused == plain, f"{name} opts={base}: frames must not depend on where the filter ran"
     # tampered index on a bitshuffled frame: indexed decoder refuses, serial decoder + gated un-filter take over
     x = O.synth(O.D_I32, 1 << 16).tobytes()
     f = bytearray(hb.Compress(x, hb.LZ4, 5, hb.BitShuffle, 4, opts=hb.OPT_INDEX_TRAILER))
@@ -463,9 +469,9 @@ def test_frame_queue_matches_one_call_api(hb, O):
 
 
 @pytest.mark.parametrize("ts", [2, 4, 8, 16])
-def test_fused_unshuffle_in_decoder_equals_separate_pass(hb, O, ts):
+def test_fused_unshuffle_in_decoder_matches_the_oracle(hb, O, ts):
     # byte-shuffled frames made of whole planes of whole 4 KiB chunks are un-shuffled by the indexed decoder itself
-    # (byte-strided stores); the result must equal the two-pass path and the oracle's decode of the same frame
+    # (byte-strided stores); the result must equal the oracle's decode of the same frame (= the input)
     n = ts * 4096 * 9
     x = O.synth(O.D_F64 if ts == 8 else O.D_F32, n // (8 if ts == 8 else 4), frame=ts).tobytes()
     if ts == 2:                                   # float32 cut into 2-byte elements barely compresses: use 16-bit steps
@@ -474,12 +480,7 @@ def test_fused_unshuffle_in_decoder_equals_separate_pass(hb, O, ts):
     a = hb.Decompress(f)
     # the index was used (not the serial fallback) -- unless the data did not compress and the frame is a memcpy frame
     assert hb.ParseHeader(f).IsMemcpy() or (hb.lib().hb_last_result_flags() & 1)
-    hb.lib().hb_debug_decode_fusion(0)
-    try:
-        b = hb.Decompress(f)
-    finally:
-        hb.lib().hb_debug_decode_fusion(1)
-    assert a == b == x
+    assert a == x
     assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), np.frombuffer(x, np.uint8))
     # a stale index (payload byte changed) must still fall back safely: serial decoder -> staged -> gated un-shuffle
     bad = bytearray(f); bad[16 + 7] ^= 0x40

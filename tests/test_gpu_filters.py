@@ -52,6 +52,12 @@ def test_kat_vectors(hb):
     assert list(hb.bitShuffle(a16, 2)) == [0, 0, 0, 0, 15, 51, 85, 0, 0, 0, 0, 0, 15, 51, 85, 255]
 
 
+def test_simd_table_kats_on_device(hb):
+    # the vectors derived from the reference's own SIMD tables (tests/golden/make_simd_kat.py) against the device kernels
+    from test_oracle import check_simd_table_kats
+    check_simd_table_kats(lambda b: hb.shuffleBytes(b, 4), lambda b: hb.unshuffleBytes(b, 4))
+
+
 def test_noop_cases(hb):
     # typeSize <= 1 or len < typeSize returns the input (shuffle.go:17-19, shuffle_test.go:318-380)
     x = bytes(range(7))

@@ -33,6 +33,38 @@ def test_filter_kats(O):
         assert got.tolist() == k["dst"], (k["kind"], k["op"], k["ts"], len(k["src"]))
 
 
+def _simd_kats():
+    doc = json.load(open(os.path.join(HERE, "golden", "simd_tables_kat.json")))
+    assert len(doc["vectors"]) >= 30
+    return doc["vectors"]
+
+
+def check_simd_table_kats(shuffle, unshuffle):
+    """The reference-held pin of the typesize-4 layout: vectors computed from the constant tables of the reference's AVX2 / NEON kernels
+    (tests/golden/make_simd_kat.py; shuffle_amd64.s:35-129, shuffle_arm64.s:28-64), which the reference asserts equal to its scalar
+    loop (shuffle_amd64_test.go:47-61).  Every plane byte the SIMD kernel writes must be what the candidate writes there; the un-shuffle
+    of the candidate's own full shuffle must give the source back over the SIMD-covered prefix, and the tables' un-shuffle of the planes too."""
+    for v in _simd_kats():
+        src = bytes.fromhex(v["src"])
+        n, ne, k = v["n"], v["n"] // 4, v["simd_elements"]
+        want = bytes.fromhex(v["shuffled_simd_bytes"])
+        got = shuffle(src)
+        assert len(got) == n
+        for j in range(4):
+            assert got[j * ne: j * ne + k] == want[j * ne: j * ne + k], (v["isa"], n, v["pattern"], j)
+        assert got[4 * ne:] == src[4 * ne:]                                      # tail bytes verbatim (shuffle.go:67-70)
+        # the planes as the tables leave them, completed by the candidate's own bytes where the SIMD kernel leaves the finisher's part
+        planes = bytearray(got)
+        back = unshuffle(bytes(planes))
+        assert back[: 4 * k] == bytes.fromhex(v["unshuffled_prefix"]) == src[: 4 * k], (v["isa"], n, v["pattern"])
+        assert back == src
+
+
+def test_simd_table_kats(O):
+    check_simd_table_kats(lambda b: O.filter(OPS["shuffle"], np.frombuffer(b, np.uint8), 4).tobytes(),
+                          lambda b: O.filter(OPS["unshuffle"], np.frombuffer(b, np.uint8), 4).tobytes())
+
+
 def test_filters_match_numpy_twin_and_invert(O):
     rng = np.random.default_rng(3)
     for ts in [1, 2, 3, 4, 5, 7, 8, 16, 255, 300]:
