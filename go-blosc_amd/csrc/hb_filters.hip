@@ -10,6 +10,10 @@
 // and parks one dword per plane in a wave-private LDS slab; the slab is then read back as one
 // ds_read_b128 per plane and stored with 16 B per lane = 1 KiB contiguous per plane per
 // instruction.  No workgroup barrier: a wave only ever reads its own slab.
+// Launch shape (round 3, tools/lab/filter_lab.hip): ONE tile per single-wave workgroup and no loop -- 262 144 workgroups per GiB
+// at typesize 4.  A streaming kernel on this chip wants the dispatcher, not a persistent grid, to deal out the work: the same
+// tile code as a grid-stride loop over 2048 workgroups of 4 waves moved 5.2 TB/s, as one tile per 64-thread workgroup 6.0
+// (a plain 16-byte copy: 5.6 against 6.4-6.5).
 // Generic kernels (any typesize, ragged ends) are byte-granular and finish what the tiles leave.
 #include "hb_common.h"
 
@@ -19,18 +23,19 @@
 // byte shuffle / unshuffle, vector path
 // ----------------------------------------------------------------------------------------------
 template <int TS>
-__global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                     uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
-    __shared__ __attribute__((aligned(16))) uint32_t slab[4][TS][256];
+__global__ __launch_bounds__(64) void k_shuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                    uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
     if (gate && *gate == 0) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t(*my)[256] = slab[wave];
-    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
+    const int lane = threadIdx.x;
+    uint32_t(*my)[256] = slab;
+    {
+        const uint64_t tile = blockIdx.x;
         const uint64_t e0 = tile * TILE_ELEMS;
         if constexpr (TS == 2) {
 #pragma unroll
             for (int it = 0; it < 2; it++) {       // 8 elements (16 B) per lane per step
-                const u32x4 v = ld16u(src + (e0 + (uint64_t)it * 512 + lane * 8) * 2);
+                const u32x4 v = ld16u_nt(src + (e0 + (uint64_t)it * 512 + lane * 8) * 2);
                 u32x2 p0, p1;
                 p0.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u); p1.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u);
                 p0.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u); p1.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
@@ -38,13 +43,17 @@ __global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, 
                 *(u32x2 *)&my[1][it * 128 + lane * 2] = p1;
             }
         } else {
+            u32x4 vin[4][TS / 4];                  // all loads of the tile in flight before the first use
+#pragma unroll
+            for (int it = 0; it < 4; it++)
+#pragma unroll
+                for (int q = 0; q < TS / 4; q++) vin[it][q] = ld16u_nt(src + (e0 + (uint64_t)it * 256 + lane * 4) * TS + q * 16);
 #pragma unroll
             for (int it = 0; it < 4; it++) {       // 4 elements (4*TS bytes) per lane per step
-                const uint8_t *p = src + (e0 + (uint64_t)it * 256 + lane * 4) * TS;
                 uint32_t w[TS];                    // w[e*TS/4 + q] = dword q of element e
 #pragma unroll
                 for (int q = 0; q < TS / 4; q++) {
-                    const u32x4 v = ld16u_nt(p + q * 16);
+                    const u32x4 v = vin[it][q];
                     w[q * 4 + 0] = v.x; w[q * 4 + 1] = v.y; w[q * 4 + 2] = v.z; w[q * 4 + 3] = v.w;
                 }
 #pragma unroll
@@ -65,22 +74,24 @@ __global__ __launch_bounds__(256) void k_shuffle_vec(uint8_t *__restrict__ dst, 
             const u32x4 v = *(const u32x4 *)&my[j][lane * 4];
             st16u_nt(dst + (uint64_t)j * ne + e0 + lane * 16, v);
         }
-        wave_sync();
     }
 }
 
 template <int TS>
-__global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                       uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
-    __shared__ __attribute__((aligned(16))) uint32_t slab[4][TS][256];
+__global__ __launch_bounds__(64) void k_unshuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                      uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
     if (gate && *gate == 0) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t(*my)[256] = slab[wave];
-    for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (uint64_t)gridDim.x * 4) {
+    const int lane = threadIdx.x;
+    uint32_t(*my)[256] = slab;
+    {
+        const uint64_t tile = blockIdx.x;
         const uint64_t e0 = tile * TILE_ELEMS;
+        u32x4 vin[TS];                             // all loads of the tile in flight before the first LDS write
 #pragma unroll
-        for (int j = 0; j < TS; j++)
-            *(u32x4 *)&my[j][lane * 4] = ld16u_nt(src + (uint64_t)j * ne + e0 + lane * 16);
+        for (int j = 0; j < TS; j++) vin[j] = ld16u_nt(src + (uint64_t)j * ne + e0 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < TS; j++) *(u32x4 *)&my[j][lane * 4] = vin[j];
         wave_sync();
         if constexpr (TS == 2) {
 #pragma unroll
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst
                 u32x4 v;                            // element e = {p0.byte e, p1.byte e}
                 v.x = __builtin_amdgcn_perm(p1.x, p0.x, 0x05010400u); v.y = __builtin_amdgcn_perm(p1.x, p0.x, 0x07030602u);
                 v.z = __builtin_amdgcn_perm(p1.y, p0.y, 0x05010400u); v.w = __builtin_amdgcn_perm(p1.y, p0.y, 0x07030602u);
-                st16u(dst + (e0 + (uint64_t)it * 512 + lane * 8) * 2, v);
+                st16u_nt(dst + (e0 + (uint64_t)it * 512 + lane * 8) * 2, v);
             }
         } else {
 #pragma unroll
@@ -111,7 +122,6 @@ __global__ __launch_bounds__(256) void k_unshuffle_vec(uint8_t *__restrict__ dst
                 }
             }
         }
-        wave_sync();
     }
 }
 
@@ -140,18 +150,40 @@ __global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ d
 // ----------------------------------------------------------------------------------------------
 // bitshuffle / bitunshuffle
 // ----------------------------------------------------------------------------------------------
-// typesize 4: one lane owns one group of 8 elements = one 32-byte window (in and out).
+// typesize 4: one lane owns one group of 8 elements = one 32-byte window (in and out).  One single-wave workgroup per 64 windows
+// (2 KiB), no loop (launch shape: see the top of the file).  The window's two 16-byte halves reach their lane through LDS, so that
+// every global access of the wave is one contiguous KiB (a lane reading its own 32 bytes makes every instruction touch half of each
+// 128-byte line: 5.6 TB/s in the lab against 6.4 for this exchange); the last, partial workgroup takes the direct path.
 template <bool INVERSE>
-__global__ __launch_bounds__(256) void k_bitshuffle4(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                     uint64_t ngroups, const uint32_t *gate) {
+__global__ __launch_bounds__(64) void k_bitshuffle4(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                    uint64_t ngroups, const uint32_t *gate) {
+    __shared__ __attribute__((aligned(16))) u32x4 slab[128];
     if (gate && *gate == 0) return;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
-        const u32x4 a = ld16u(src + g * 32), b = ld16u(src + g * 32 + 16);
+    const int lane = threadIdx.x;
+    const uint64_t g0 = (uint64_t)blockIdx.x * 64;
+    if (g0 + 64 <= ngroups) {
+        const uint8_t *s = src + g0 * 32;
+        const u32x4 v0 = ld16u_nt(s + lane * 16), v1 = ld16u_nt(s + 1024 + lane * 16);
+        slab[lane] = v0; slab[64 + lane] = v1;
+        wave_sync();
+        const u32x4 a = slab[2 * lane], b = slab[2 * lane + 1];
         u32x4 oa, ob;
         bitshuffle4_window<INVERSE>(a, b, oa, ob);
-        st16u(dst + g * 32, oa);
-        st16u(dst + g * 32 + 16, ob);
+        wave_sync();
+        slab[2 * lane] = oa; slab[2 * lane + 1] = ob;
+        wave_sync();
+        uint8_t *d = dst + g0 * 32;
+        st16u_nt(d + lane * 16, slab[lane]);
+        st16u_nt(d + 1024 + lane * 16, slab[64 + lane]);
+    } else {
+        const uint64_t g = g0 + lane;
+        if (g < ngroups) {
+            const u32x4 a = ld16u(src + g * 32), b = ld16u(src + g * 32 + 16);
+            u32x4 oa, ob;
+            bitshuffle4_window<INVERSE>(a, b, oa, ob);
+            st16u(dst + g * 32, oa);
+            st16u(dst + g * 32 + 16, ob);
+        }
     }
 }
 
@@ -195,9 +227,9 @@ static inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigne
 
 template <int TS>
 static void launch_shuffle_vec(bool inverse, uint8_t *dst, const uint8_t *src, uint64_t ne, uint64_t ntiles, const uint32_t *gate, hipStream_t s) {
-    const unsigned grid = grid_for(ntiles, 4, 256 * 8);
-    if (!inverse) hipLaunchKernelGGL(k_shuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles, gate);
-    else hipLaunchKernelGGL(k_unshuffle_vec<TS>, dim3(grid), dim3(256), 0, s, dst, src, ne, ntiles, gate);
+    const unsigned grid = (unsigned)ntiles;             // one tile per single-wave workgroup (n < 4 GiB: at most 2^21 tiles)
+    if (!inverse) hipLaunchKernelGGL(k_shuffle_vec<TS>, dim3(grid), dim3(64), 0, s, dst, src, ne, ntiles, gate);
+    else hipLaunchKernelGGL(k_unshuffle_vec<TS>, dim3(grid), dim3(64), 0, s, dst, src, ne, ntiles, gate);
 }
 
 static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n, int typesize, const uint32_t *gate, hipStream_t s);
@@ -244,9 +276,9 @@ static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n
         const bool inv = (op == HB_OP_BITUNSHUFFLE);
         const uint64_t ng = ne / 8;
         if (ts == 4 && ng > 0) {
-            const unsigned grid = grid_for(ng, 256, 256 * 16);
-            if (!inv) hipLaunchKernelGGL(k_bitshuffle4<false>, dim3(grid), dim3(256), 0, s, dst, src, ng, gate);
-            else hipLaunchKernelGGL(k_bitshuffle4<true>, dim3(grid), dim3(256), 0, s, dst, src, ng, gate);
+            const unsigned grid = (unsigned)((ng + 63) / 64);
+            if (!inv) hipLaunchKernelGGL(k_bitshuffle4<false>, dim3(grid), dim3(64), 0, s, dst, src, ng, gate);
+            else hipLaunchKernelGGL(k_bitshuffle4<true>, dim3(grid), dim3(64), 0, s, dst, src, ng, gate);
             if (ng * 32 < n)   // leftover elements + tail bytes only (g_begin = ng: no groups)
                 hipLaunchKernelGGL(k_bitshuffle_generic, dim3(1), dim3(256), 0, s, dst, src, (uint64_t)n, ng, 4u,
                                    inv ? 1 : 0, ng, gate);

@@ -63,11 +63,16 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
     plan->mode = DEC_INDEXED;
 }
 
+#ifndef DEC_IN_WIN
 #define DEC_IN_WIN  2560u                // bytes of a unit's stream slice that are staged in LDS at a time (the window moves)
+#endif
 #define DEC_IN_MARGIN 320u               // a token closer than this to the end of the window is parsed after re-staging
 #define DEC_OUT_MAX HB_CHUNK             // largest output a unit may have
+#ifndef DEC_WAVES
+#define DEC_WAVES 5
+#endif
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES))) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
                                                     DecPlan *plan, int bun4, int ush, uint32_t plane_mask) {
     // ush != 0: the frame was byte-shuffled with typesize `ush` and has only whole planes of whole chunks; the un-shuffle is

@@ -163,13 +163,13 @@ def test_forged_geometry_is_refused_before_anything_is_sized(hb, O, cb):
     forged = struct.pack("<BBBBIII", 2, 1, 0x21, 8, n, 4, 16 + 64)       # blocksize below typesize
     with pytest.raises(hb.ErrInvalidData):
         hb.CBloscDecompress(forged + bytes(64))
-    import torch
-    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    buf = hb.PinnedBuffer(4096)               # (the record is refused before any of these addresses is used)
     for ts, bsz, want in ((0, 4096, -2), (4, 0, -2)):
         hdr = hb.CBloscHeader()
         hdr.version, hdr.versionlz, hdr.flags, hdr.typesize, hdr.nbytes, hdr.blocksize, hdr.cbytes, hdr.codec_format = 2, 1, 0x21, ts, 1024, bsz, 64, 1
-        rc = L.hb_cblosc_decompress_dev(ctypes.byref(hdr), buf.data_ptr(), 64, buf.data_ptr() + 1024, 1024, buf.data_ptr() + 2048, 2048, buf.data_ptr() + 512, None)
+        rc = L.hb_cblosc_decompress_dev(ctypes.byref(hdr), buf.ptr, 64, buf.ptr + 1024, 1024, buf.ptr + 2048, 2048, buf.ptr + 512, None)
         assert rc == want, (ts, bsz, rc)
+    buf.close()
 
 
 def test_frames_written_here_are_read_by_the_library(hb, O, cb):
