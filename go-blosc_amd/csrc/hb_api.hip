@@ -116,6 +116,10 @@ bool overlap(const void *a, size_t na, const void *b, size_t nb) {
 }  // namespace
 
 unsigned hb_dbg_plane_mask() { return g_plane_mask; }
+// the device-scratch cache and the device selection for the other translation units' host-pointer entry points (hb_batch.hip)
+void *hb_pool_take(int dev, size_t bytes, size_t *got) { return pool_get(dev, bytes, got); }
+void hb_pool_give(int dev, void *p, size_t bytes) { pool_put(dev, p, bytes); }
+int hb_select_device(int device) { return select_device(device); }
 
 // ---- stage timing -------------------------------------------------------------------------
 namespace {

@@ -116,9 +116,15 @@ __device__ __forceinline__ void bitshuffle4_window(const u32x4 a, const u32x4 b,
 void hb_prof_begin(const char *stage, hipStream_t s);   // no-ops unless hb_profile_enable(1)
 void hb_prof_end(hipStream_t s);
 
+void *hb_pool_take(int dev, size_t bytes, size_t *got);  // hb_api.hip: cached device scratch of the host-pointer entry points
+void hb_pool_give(int dev, void *p, size_t bytes);
+int hb_select_device(int device);                        // hipSetDevice with the ABI's error codes
 unsigned hb_dbg_plane_mask();                            // hb_debug_plane_mask(): byte planes the fused LZ4 kernels work on (timing only)
 
 // ---- internal launch API shared between translation units ----
 int hb_launch_filter(int op, uint8_t *d_dst, const uint8_t *d_src, size_t n, int typesize, hipStream_t s);
 // same, but every kernel returns immediately unless *gate != 0 (gate is read on the device)
 int hb_launch_filter_gated(int op, uint8_t *d_dst, const uint8_t *d_src, size_t n, int typesize, const uint32_t *gate, hipStream_t s);
+// the same filter on a batch of independent buffers (device array of jobs; gate as above, NULL = always)
+struct hb_filter_job { uint8_t *dst; const uint8_t *src; uint64_t n; const uint32_t *gate; };
+int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_t max_n, int typesize, hipStream_t s);

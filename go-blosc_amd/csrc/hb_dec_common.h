@@ -22,6 +22,22 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
 // hb_lz4_sym.hip: decodes a block whose rebuilt index did not hold (a foreign block) from the verified token chain
 int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_work, int mark_post, hipStream_t s);
 
+// ---- batches of frames in one set of launches (hb_decompress_frames_batch_dev): frame f of the batch as the kernels see it ----
+struct DecBatchFrame {
+    const uint8_t *src; uint64_t n_src;      // the payload: an LZ4 block (or the stored bytes of a memcpy frame)
+    uint8_t *dst;                            // target of the indexed decoder (final bytes when the un-filter is fused into it)
+    uint8_t *serial_dst;                     // target of the stream / serial decoders (bytes still filtered)
+    const uint8_t *index; uint64_t index_bytes;   // restart index behind NBytesComp, if the frame brought one
+    DecPlan *plan; hb_result *result;
+    uint32_t nbytes;                         // NBytesOrig: capacity and expected length (blosc.go:429-431)
+    uint32_t unit0, nunits;                  // place in the flat unit space of the batch (nunits = 0: no index, one wavefront decodes the stream)
+    int32_t preset;                          // 1: decode; else the status the host already knows (memcpy frames, blosc.go:398-400)
+    int32_t ush, bun4;                       // un-filter fused into the indexed decoder (as hb_dec_args)
+    int32_t post_needed, pad;                // the stream / serial decoders' output still needs the (gated) un-filter pass
+};
+size_t hb_lz4_dec_batch_units(int nframes, const DecBatchFrame *h, uint32_t *unit0_out);
+int hb_launch_lz4_decode_batch_indexed(int nframes, const DecBatchFrame *d_bf, uint32_t *d_unit_frame, uint32_t total_units, int any_ush, hipStream_t s);
+
 #define DTQ 96                           // token queue slots: < 64 queued before a window is parsed; a 64-byte window adds <= 22 LZ4 tokens or <= 32 Snappy elements
 
 #define DLITCAP 16u

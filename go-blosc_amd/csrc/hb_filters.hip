@@ -23,14 +23,9 @@
 // byte shuffle / unshuffle, vector path
 // ----------------------------------------------------------------------------------------------
 template <int TS>
-__global__ __launch_bounds__(64) void k_shuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                    uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
-    __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
-    if (gate && *gate == 0) return;
-    const int lane = threadIdx.x;
-    uint32_t(*my)[256] = slab;
+__device__ __forceinline__ void shuffle_tile(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, const uint64_t ne, const uint64_t tile,
+                                             uint32_t (*my)[256], const int lane) {
     {
-        const uint64_t tile = blockIdx.x;
         const uint64_t e0 = tile * TILE_ELEMS;
         if constexpr (TS == 2) {
 #pragma unroll
@@ -76,16 +71,18 @@ __global__ __launch_bounds__(64) void k_shuffle_vec(uint8_t *__restrict__ dst, c
         }
     }
 }
-
 template <int TS>
-__global__ __launch_bounds__(64) void k_unshuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                      uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
+__global__ __launch_bounds__(64) void k_shuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                    uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
     __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
     if (gate && *gate == 0) return;
-    const int lane = threadIdx.x;
-    uint32_t(*my)[256] = slab;
+    shuffle_tile<TS>(dst, src, ne, blockIdx.x, slab, threadIdx.x);
+}
+
+template <int TS>
+__device__ __forceinline__ void unshuffle_tile(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, const uint64_t ne, const uint64_t tile,
+                                               uint32_t (*my)[256], const int lane) {
     {
-        const uint64_t tile = blockIdx.x;
         const uint64_t e0 = tile * TILE_ELEMS;
         u32x4 vin[TS];                             // all loads of the tile in flight before the first LDS write
 #pragma unroll
@@ -124,14 +121,31 @@ __global__ __launch_bounds__(64) void k_unshuffle_vec(uint8_t *__restrict__ dst,
         }
     }
 }
+template <int TS>
+__global__ __launch_bounds__(64) void k_unshuffle_vec(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                      uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
+    if (gate && *gate == 0) return;
+    unshuffle_tile<TS>(dst, src, ne, blockIdx.x, slab, threadIdx.x);
+}
+
+// ---- the same tiles for a batch of buffers (hb_*_frames_batch_dev): job blockIdx.y, tile blockIdx.x of that job ----
+template <int TS, bool INVERSE>
+__global__ __launch_bounds__(64) void k_shuffle_vec_batch(const hb_filter_job *__restrict__ jobs) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
+    const hb_filter_job j = jobs[blockIdx.y];
+    if (j.gate && *j.gate == 0) return;
+    const uint64_t ne = j.n / TS;
+    if (blockIdx.x >= ne / TILE_ELEMS) return;
+    if (INVERSE) unshuffle_tile<TS>(j.dst, j.src, ne, blockIdx.x, slab, threadIdx.x);
+    else shuffle_tile<TS>(j.dst, j.src, ne, blockIdx.x, slab, threadIdx.x);
+}
 
 // ----------------------------------------------------------------------------------------------
 // byte shuffle / unshuffle, generic path: elements [e_begin, e_end) of every plane + the tail bytes
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                         uint64_t n, uint64_t ne, uint32_t ts,
-                                                         uint64_t e_begin, int inverse, const uint32_t *gate) {
-    if (gate && *gate == 0) return;
+__device__ __forceinline__ void shuffle_generic_body(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                     uint64_t n, uint64_t ne, uint32_t ts, uint64_t e_begin, int inverse) {
     const uint64_t cnt = ne - e_begin, total = cnt * ts, tail0 = ne * ts;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -146,6 +160,21 @@ __global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ d
     for (uint64_t t = tail0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
         dst[t] = src[t];                // shuffle.go:67-70 / :127-130
 }
+__global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                         uint64_t n, uint64_t ne, uint32_t ts,
+                                                         uint64_t e_begin, int inverse, const uint32_t *gate) {
+    if (gate && *gate == 0) return;
+    shuffle_generic_body(dst, src, n, ne, ts, e_begin, inverse);
+}
+// batch: job blockIdx.y; vec != 0: the vector kernel has done the whole tiles of every job
+__global__ __launch_bounds__(256) void k_shuffle_generic_batch(const hb_filter_job *__restrict__ jobs, uint32_t ts, int inverse, int vec) {
+    const hb_filter_job j = jobs[blockIdx.y];
+    if (j.gate && *j.gate == 0) return;
+    const uint64_t ne = j.n / ts;
+    const uint64_t e_begin = vec ? ne / TILE_ELEMS * TILE_ELEMS : 0;
+    if (j.n == 0 || (e_begin == ne && ne * ts == j.n)) return;
+    shuffle_generic_body(j.dst, j.src, j.n, ne, ts, e_begin, inverse);
+}
 
 // ----------------------------------------------------------------------------------------------
 // bitshuffle / bitunshuffle
@@ -155,10 +184,7 @@ __global__ __launch_bounds__(256) void k_shuffle_generic(uint8_t *__restrict__ d
 // every global access of the wave is one contiguous KiB (a lane reading its own 32 bytes makes every instruction touch half of each
 // 128-byte line: 5.6 TB/s in the lab against 6.4 for this exchange); the last, partial workgroup takes the direct path.
 template <bool INVERSE>
-__global__ __launch_bounds__(64) void k_bitshuffle4(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                    uint64_t ngroups, const uint32_t *gate) {
-    __shared__ __attribute__((aligned(16))) u32x4 slab[128];
-    if (gate && *gate == 0) return;
+__device__ __forceinline__ void bitshuffle4_tile(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, const uint64_t ngroups, u32x4 *slab) {
     const int lane = threadIdx.x;
     const uint64_t g0 = (uint64_t)blockIdx.x * 64;
     if (g0 + 64 <= ngroups) {
@@ -186,12 +212,26 @@ __global__ __launch_bounds__(64) void k_bitshuffle4(uint8_t *__restrict__ dst, c
         }
     }
 }
+template <bool INVERSE>
+__global__ __launch_bounds__(64) void k_bitshuffle4(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                    uint64_t ngroups, const uint32_t *gate) {
+    __shared__ __attribute__((aligned(16))) u32x4 slab[128];
+    if (gate && *gate == 0) return;
+    bitshuffle4_tile<INVERSE>(dst, src, ngroups, slab);
+}
+template <bool INVERSE>
+__global__ __launch_bounds__(64) void k_bitshuffle4_batch(const hb_filter_job *__restrict__ jobs) {
+    __shared__ __attribute__((aligned(16))) u32x4 slab[128];
+    const hb_filter_job j = jobs[blockIdx.y];
+    if (j.gate && *j.gate == 0) return;
+    const uint64_t ng = j.n / 32;
+    if ((uint64_t)blockIdx.x * 64 >= ng) return;
+    bitshuffle4_tile<INVERSE>(j.dst, j.src, ng, slab);
+}
 
 // any typesize: one thread per (group, byte position).  shuffle.go:184-200 / :261-277
-__global__ __launch_bounds__(256) void k_bitshuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
-                                                            uint64_t n, uint64_t ngroups, uint32_t ts, int inverse,
-                                                            uint64_t g_begin, const uint32_t *gate) {
-    if (gate && *gate == 0) return;
+__device__ __forceinline__ void bitshuffle_generic_body(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                        uint64_t n, uint64_t ngroups, uint32_t ts, int inverse, uint64_t g_begin) {
     const uint64_t total = ngroups * ts, done = ngroups * 8 * ts;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t idx = g_begin * ts + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -213,6 +253,20 @@ __global__ __launch_bounds__(256) void k_bitshuffle_generic(uint8_t *__restrict_
     }
     for (uint64_t t = done + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride)
         dst[t] = src[t];                // leftover elements + tail bytes, shuffle.go:206-216 / :282-292
+}
+__global__ __launch_bounds__(256) void k_bitshuffle_generic(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                            uint64_t n, uint64_t ngroups, uint32_t ts, int inverse,
+                                                            uint64_t g_begin, const uint32_t *gate) {
+    if (gate && *gate == 0) return;
+    bitshuffle_generic_body(dst, src, n, ngroups, ts, inverse, g_begin);
+}
+// batch: job blockIdx.y; vec != 0 (typesize 4): k_bitshuffle4_batch has done every whole window, only leftovers and tails remain
+__global__ __launch_bounds__(256) void k_bitshuffle_generic_batch(const hb_filter_job *__restrict__ jobs, uint32_t ts, int inverse, int vec) {
+    const hb_filter_job j = jobs[blockIdx.y];
+    if (j.gate && *j.gate == 0) return;
+    const uint64_t ng = j.n / ts / 8;
+    if (j.n == 0 || (vec && ng * 8 * ts == j.n)) return;
+    bitshuffle_generic_body(j.dst, j.src, j.n, ng, ts, inverse, vec ? ng : 0);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -286,6 +340,46 @@ static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n
             const uint64_t items = ng * ts + (n - ng * 8 * ts);
             hipLaunchKernelGGL(k_bitshuffle_generic, dim3(grid_for(items, 256, 256 * 16)), dim3(256), 0, s,
                                dst, src, (uint64_t)n, ng, (uint32_t)ts, inv ? 1 : 0, (uint64_t)0, gate);
+        }
+    }
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}
+
+// ---- batches (hb_*_frames_batch_dev): the same filter on `njobs` independent buffers in one or two launches.  d_jobs: device array;
+// max_n: the largest job (sizes the grid; jobs smaller than that leave their surplus workgroups at once).  Identity cases
+// (typesize <= 1, n < typesize: shuffle.go:17-19) are the caller's: it points the consumer at the source instead. ----
+int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_t max_n, int typesize, hipStream_t s) {
+    if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
+    if (njobs <= 0 || max_n == 0 || typesize <= 1) return HB_OK;
+    const uint64_t ts = (uint64_t)typesize;
+    const bool inv = op == HB_OP_UNSHUFFLE || op == HB_OP_BITUNSHUFFLE;
+    for (int j0 = 0; j0 < njobs; j0 += 65535) {                       // gridDim.y <= 65535
+        const unsigned ny = (unsigned)(njobs - j0 < 65535 ? njobs - j0 : 65535);
+        const hb_filter_job *jb = d_jobs + j0;
+        if (op == HB_OP_SHUFFLE || op == HB_OP_UNSHUFFLE) {
+            const bool vec = ts == 2 || ts == 4 || ts == 8 || ts == 16;
+            const uint64_t mt = max_n / ts / TILE_ELEMS;
+            if (vec && mt) {
+                const dim3 g((unsigned)mt, ny);
+                switch (ts) {
+                case 2: if (inv) hipLaunchKernelGGL((k_shuffle_vec_batch<2, true>), g, dim3(64), 0, s, jb); else hipLaunchKernelGGL((k_shuffle_vec_batch<2, false>), g, dim3(64), 0, s, jb); break;
+                case 4: if (inv) hipLaunchKernelGGL((k_shuffle_vec_batch<4, true>), g, dim3(64), 0, s, jb); else hipLaunchKernelGGL((k_shuffle_vec_batch<4, false>), g, dim3(64), 0, s, jb); break;
+                case 8: if (inv) hipLaunchKernelGGL((k_shuffle_vec_batch<8, true>), g, dim3(64), 0, s, jb); else hipLaunchKernelGGL((k_shuffle_vec_batch<8, false>), g, dim3(64), 0, s, jb); break;
+                default: if (inv) hipLaunchKernelGGL((k_shuffle_vec_batch<16, true>), g, dim3(64), 0, s, jb); else hipLaunchKernelGGL((k_shuffle_vec_batch<16, false>), g, dim3(64), 0, s, jb); break;
+                }
+            }
+            // what the tiles leave (or everything, for the other typesizes): byte-granular, a few workgroups per job
+            const uint64_t items = vec ? (uint64_t)TILE_ELEMS * ts + ts : max_n;
+            hipLaunchKernelGGL(k_shuffle_generic_batch, dim3(grid_for(items, 256 * 16, 64), ny), dim3(256), 0, s, jb, (uint32_t)ts, inv ? 1 : 0, vec ? 1 : 0);
+        } else {
+            const bool vec = ts == 4;
+            if (vec && max_n / 32) {
+                const dim3 g((unsigned)((max_n / 32 + 63) / 64), ny);
+                if (inv) hipLaunchKernelGGL(k_bitshuffle4_batch<true>, g, dim3(64), 0, s, jb); else hipLaunchKernelGGL(k_bitshuffle4_batch<false>, g, dim3(64), 0, s, jb);
+            }
+            const uint64_t items = vec ? 64 : max_n;
+            hipLaunchKernelGGL(k_bitshuffle_generic_batch, dim3(grid_for(items, 256 * 16, 64), ny), dim3(256), 0, s, jb, (uint32_t)ts, inv ? 1 : 0, vec ? 1 : 0);
         }
     }
     HB_HIP_TRY(hipGetLastError());

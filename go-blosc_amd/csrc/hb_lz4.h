@@ -39,6 +39,11 @@ int64_t hb_zstd_compress_frame(const void *src, size_t n, void *dst, size_t cap,
                                unsigned opts, int device);
 int64_t hb_zstd_decompress_frame(const void *frame, const hb_header &h, void *dst, size_t cap, int typesize_override, int device);
 
+// batches of frames in one set of launches (hb_lz4_enc.hip / hb_batch.hip)
+struct hb_batch_frame { const uint8_t *src; size_t n; uint8_t *dst; size_t cap; hb_result *result; };
+size_t hb_lz4_enc_batch_workspace(int nframes, const size_t *n, int typesize);
+int hb_launch_lz4_encode_batch(int nframes, const hb_batch_frame *fr, int codec, int level, int shuffle, int typesize, unsigned opts,
+                               uint8_t *work, size_t work_bytes, hipStream_t s);
 size_t hb_lz4_enc_workspace(size_t n);
 size_t hb_lz4_dec_workspace(size_t n_out);
 size_t hb_lz4_index_bound(size_t n);

@@ -33,8 +33,8 @@ size_t hb_lz4_dec_workspace(size_t n_out) { return 256 + hb_lz4_region_workspace
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return ld4u(p); }
 
 // 1 thread: is there a usable index?
-__global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_bytes, uint64_t n_src, uint64_t cap,
-                           DecPlan *plan, hb_result *result) {
+__device__ __forceinline__ void dec_plan_check(const uint8_t *__restrict__ index, uint64_t index_bytes, uint64_t n_src, uint64_t cap,
+                                               DecPlan *plan, hb_result *result) {
     plan->mode = DEC_SERIAL; plan->fail = 0; plan->nunits = 0; plan->nbytes = 0; plan->post = 0; plan->stride = 1;
     result->status = HB_OK; result->flags = 0; result->bytes = 0; result->total_bytes = 0; result->reserved = 0;
     if (!index || index_bytes < HB_IDX_HDR_BYTES + 2 * HB_IDX_ENTRY) return;
@@ -62,6 +62,10 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
     plan->stride = P;
     plan->mode = DEC_INDEXED;
 }
+__global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_bytes, uint64_t n_src, uint64_t cap,
+                           DecPlan *plan, hb_result *result) {
+    dec_plan_check(index, index_bytes, n_src, cap, plan, result);
+}
 
 #ifndef DEC_IN_WIN
 #define DEC_IN_WIN  2560u                // bytes of a unit's stream slice that are staged in LDS at a time (the window moves)
@@ -71,6 +75,201 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
 #ifndef DEC_WAVES
 #define DEC_WAVES 5
 #endif
+
+// One index unit (4 KiB of output), one wavefront: everything the indexed decoder does for unit `u` of a block.  The block comes as a
+// DecCtx so that the same code serves one frame (k_dec_indexed: the context is the kernel's arguments) and batches of frames
+// (k_dec_indexed_batch: the context of the unit's frame).
+struct DecCtx {
+    const uint8_t *src; uint64_t n_src;      // the LZ4 block
+    uint8_t *dst;                            // decoded (and, with a fused un-filter, un-filtered) bytes
+    const uint8_t *ent;                      // index entries
+    DecPlan *plan;
+    uint32_t nbytes, nunits;
+    int bun4, ush;
+};
+__device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint8_t *s_in, uint8_t *s_out, uint2 *s_tq, const int lane) {
+    const uint8_t *const src = c.src; const uint64_t n_src = c.n_src; uint8_t *const dst = c.dst; const uint8_t *const ent = c.ent;
+    DecPlan *const plan = c.plan; const uint32_t nbytes = c.nbytes, nunits = c.nunits; const int bun4 = c.bun4, ush = c.ush;
+    const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
+    // wave-uniform values that come out of vector loads are moved to scalar registers: the compiler cannot know
+    // they are uniform, and would otherwise run the whole state machine on the vector side under exec masks
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+    const uint32_t s0 = RFL(e0.x), d0 = RFL(e0.y), s1 = RFL(e1.x), d1 = RFL(e1.y), rem1 = RFL(e1.z), tok1 = RFL(e1.w);
+    uint32_t rem = RFL(e0.z), tokpos = RFL(e0.w);
+    const bool last = (u + 1 == nunits);
+    bool ok = s0 <= s1 && s1 <= n_src && d0 <= d1 && d1 <= nbytes && (d1 - d0) <= DEC_OUT_MAX;
+    if (u == 0) ok = ok && s0 == 0 && d0 == 0 && rem == HB_IDX_AT_TOKEN;
+    if (last) ok = ok && s1 == n_src && d1 == nbytes;
+    if (rem != HB_IDX_AT_TOKEN && tokpos >= n_src) ok = false;
+    if (bun4 && ((d0 | d1) & 31u)) ok = false;              // fused un-filter works on whole 32-byte windows
+    const uint32_t ne = ush ? nbytes / (uint32_t)ush : 1u;  // bytes per plane
+    const uint32_t pj = ush ? d0 / ne : 0u;                 // my plane
+    if (ush && (pj >= (uint32_t)ush || d1 > (pj + 1u) * ne)) ok = false;   // a unit never straddles two planes
+    uint8_t *const udst = ush ? dst + (size_t)(d0 - pj * ne) * (uint32_t)ush + pj : dst + d0;
+    if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); return; }
+    const uint32_t slen = s1 - s0, outlen = d1 - d0;
+    const uint8_t *g = src + s0;
+
+    // the whole unit lies inside one literal run (incompressible chunk): HBM -> HBM, no LDS
+    if (rem != HB_IDX_AT_TOKEN && rem >= outlen) {
+        const uint32_t left = rem - outlen;
+        bool fine = slen == outlen;
+        // a block that ends inside/after a literal run is accepted only if that token announces no match
+        // (UncompressBlock: si == len(src) && matchNibble == 0; oracle/blosc_oracle.c ob_lz4_decompress) -- else the serial decoder decides
+        if (last) fine = fine && left == 0 && (RFL((uint32_t)src[tokpos]) & 15u) == 0u; else fine = fine && rem1 == left && tok1 == tokpos;
+        if (!fine) { if (lane == 0) atomicExch(&plan->fail, 1u); return; }
+        if (ush) {                                          // wide loads (any alignment) into the image, then the strided stores
+            for (uint32_t i = lane * 16u; i < outlen; i += 1024u) {
+                if (i + 16u <= outlen) *(u32x4 *)(s_out + i) = ld16u(g + i);
+                else for (uint32_t r = i; r < outlen; r++) s_out[r] = g[r];
+            }
+            wave_sync();
+            for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
+            wave_sync();
+        }
+        else if (!bun4) wave_copy_g2g(dst + d0, g, outlen, lane);
+        else {
+            for (uint32_t w = lane; w < outlen / 32u; w += 64) {
+                u32x4 oa, ob;
+                bitshuffle4_window<true>(ld16u(g + 32u * w), ld16u(g + 32u * w + 16u), oa, ob);
+                st16u(dst + d0 + 32u * w, oa);
+                st16u(dst + d0 + 32u * w + 16u, ob);
+            }
+        }
+        return;
+    }
+
+    // stage a window of the slice (all of it, for a dense unit); `at` = slice position the window has to start at.
+    // LDS byte k of s_in is global byte g - sh + a16 + k, a16 a multiple of 16: 16-byte aligned vector loads.
+    const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
+    uint32_t wlo = 0, staged = 0;                           // the window holds slice positions [wlo, staged)
+    int shw = 0;                                            // LDS index of slice position p = p + shw
+    auto stage = [&](const uint32_t at) __attribute__((always_inline)) {
+        wave_sync();
+        const uint32_t a16 = (sh + at) & ~15u;
+        const uint32_t avail = sh + slen - a16;
+        const uint32_t cnt = avail < DEC_IN_WIN ? avail : DEC_IN_WIN;
+        const u32x4 *ga = (const u32x4 *)(g - sh + a16);
+        const uint32_t nv = (cnt + 15u) >> 4;
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_in)[i] = ga[i];
+        wlo = a16 > sh ? a16 - sh : 0u;
+        staged = a16 + cnt - sh;
+        shw = (int)sh - (int)a16;
+        wave_sync();
+    };
+    stage(0u);
+    uint32_t tok = 0;
+    if (rem != HB_IDX_AT_TOKEN) tok = RFL((uint32_t)src[tokpos]);
+#define INB(i) s_in[(uint32_t)((int)(i) + shw)]              /* stream byte at slice position i (inside the window) */
+    uint32_t si = 0, di = 0;
+    bool at_token = false;       // state when the unit stops
+    bool done = false;
+
+    // State machine.  slow != 0: handle ONE sequence of any shape (length extensions of any size, bytes
+    // outside the staged window, end of the unit inside a literal run); slow == 2 starts at a token,
+    // slow == 1 inside the literal run (rem, tok) the unit begins in.  slow == 0: the window parser below.
+    int slow = 1;
+    uint32_t nq = 0;                                        // tokens queued in s_tq
+    if (rem == HB_IDX_AT_TOKEN) { rem = 0; slow = 0; }
+    while (ok && !done) {
+        if (slow) {
+            if (slow == 2) {
+                if (si >= slen) { ok = false; break; }
+                tokpos = s0 + si;
+                tok = RFL((uint32_t)((si >= wlo && si < staged) ? INB(si) : g[si]));
+                si++;
+                rem = tok >> 4;
+                if (rem == 15u && !dec_read_ext(s_in, shw, wlo, staged, g, slen, si, rem, lane)) { ok = false; break; }
+            }
+            slow = 0;
+            {   // literal phase
+                const uint32_t take = min(rem, outlen - di);
+                if (take > slen - si) { ok = false; break; }
+                if (si >= wlo && si + take <= staged) { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = INB(si + i); }
+                else { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = g[si + i]; }
+                si += take; di += take; rem -= take;
+            }
+            if (rem > 0 || di == outlen) { at_token = false; done = true; break; }
+            // match phase
+            if (slen - si < 2) { ok = false; break; }             // also: block ends after literals -> serial decides
+            const uint32_t b0 = RFL((uint32_t)((si >= wlo && si < staged) ? INB(si) : g[si]));
+            const uint32_t b1 = RFL((uint32_t)((si + 1 >= wlo && si + 1 < staged) ? INB(si + 1) : g[si + 1]));
+            const uint32_t offset = b0 | (b1 << 8);
+            si += 2;
+            uint32_t mlen = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u && !dec_read_ext(s_in, shw, wlo, staged, g, slen, si, mlen, lane)) { ok = false; break; }
+            if (offset == 0 || offset > di || mlen > outlen - di) { ok = false; break; }
+            dec_match_copy(s_out, di, offset, mlen, lane);
+            di += mlen;
+            // peek: a next token with a multi-byte match extension would come straight back from the window parser
+            // (highly compressible units are a handful of such tokens): stay on this path
+            if (si >= wlo && si + 4u <= staged && di < outlen) {
+                const uint32_t t2 = RFL((uint32_t)INB(si)), l2 = t2 >> 4;
+                if (l2 < 15u && (t2 & 15u) == 15u) {
+                    const uint32_t op = si + 1u + l2;
+                    if (op + 3u <= staged && RFL((uint32_t)INB(op + 2u)) == 255u) slow = 2;
+                }
+            }
+            continue;
+        }
+        if (nq == 0u && staged < slen && si + DEC_IN_MARGIN > staged) {     // move the window (queued tokens point into it)
+            stage(si);
+        }
+        const bool stop = dec_fill(s_in, (uint32_t)shw, staged, slen, si, nq, s_tq, lane);
+        bool rewound = false;
+        ok = dec_drain(s_in, shw, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
+        if (!ok) break;
+        if (rewound) { slow = 2; continue; }
+        if (stop) {
+            if (si == slen || di == outlen) { at_token = true; done = true; }
+            else if (staged < slen && si + DEC_IN_MARGIN > staged) continue;   // stopped at the end of the window, not at a complex token
+            else slow = 2;
+        }
+    }
+    // end-state check against the next entry
+    if (ok) {
+        ok = (si == slen) && (di == outlen);
+        if (last) ok = ok && (at_token || (rem == 0 && (tok & 15u) == 0u));   // ends after literals: the token must announce no match
+        else if (at_token) ok = ok && rem1 == HB_IDX_AT_TOKEN;
+        else ok = ok && rem1 == rem && tok1 == tokpos;
+    }
+    if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); wave_sync(); return; }
+    wave_sync();
+    if (bun4) {                                             // fused bit-unshuffle: every window in place
+        for (uint32_t w = lane; w < outlen / 32u; w += 64) {
+            u32x4 oa, ob;
+            bitshuffle4_window<true>(((const u32x4 *)s_out)[2 * w], ((const u32x4 *)s_out)[2 * w + 1], oa, ob);
+            ((u32x4 *)s_out)[2 * w] = oa;
+            ((u32x4 *)s_out)[2 * w + 1] = ob;
+        }
+        wave_sync();
+    }
+    // flush the chunk image
+    if (ush) {
+        for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
+    } else {
+        uint8_t *o = dst + d0;
+        uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);
+        if (head > outlen) head = outlen;
+        if ((uint32_t)lane < head) o[lane] = s_out[lane];
+        const uint32_t body = (outlen - head) >> 4;
+        if (head == 0) { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + i * 16u) = *(const u32x4 *)(s_out + i * 16u); }
+        else {
+            for (uint32_t i = lane; i < body; i += 64) {
+                const uint8_t *q = s_out + head + i * 16u;
+                u32x4 v;
+                v.x = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                v.y = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+                v.z = (uint32_t)q[8] | ((uint32_t)q[9] << 8) | ((uint32_t)q[10] << 16) | ((uint32_t)q[11] << 24);
+                v.w = (uint32_t)q[12] | ((uint32_t)q[13] << 8) | ((uint32_t)q[14] << 16) | ((uint32_t)q[15] << 24);
+                *(u32x4 *)(o + head + i * 16u) = v;
+            }
+        }
+        const uint32_t done_b = head + body * 16u;
+        if (done_b + lane < outlen) o[done_b + lane] = s_out[done_b + lane];
+    }
+    wave_sync();
+}
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES))) void k_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src,
                                                     uint8_t *__restrict__ dst, const uint8_t *__restrict__ index,
@@ -121,186 +320,83 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES)))
             u = j * nblk + b;
             if (!((plane_mask >> j) & 1u)) continue;            // hb_debug_plane_mask: per-plane timing
         }
-        const u32x4 e0 = ld16u(ent + 16 * (size_t)u), e1 = ld16u(ent + 16 * (size_t)(u + 1));
-        // wave-uniform values that come out of vector loads are moved to scalar registers: the compiler cannot know
-        // they are uniform, and would otherwise run the whole state machine on the vector side under exec masks
-#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-        const uint32_t s0 = RFL(e0.x), d0 = RFL(e0.y), s1 = RFL(e1.x), d1 = RFL(e1.y), rem1 = RFL(e1.z), tok1 = RFL(e1.w);
-        uint32_t rem = RFL(e0.z), tokpos = RFL(e0.w);
-        const bool last = (u + 1 == nunits);
-        bool ok = s0 <= s1 && s1 <= n_src && d0 <= d1 && d1 <= nbytes && (d1 - d0) <= DEC_OUT_MAX;
-        if (u == 0) ok = ok && s0 == 0 && d0 == 0 && rem == HB_IDX_AT_TOKEN;
-        if (last) ok = ok && s1 == n_src && d1 == nbytes;
-        if (rem != HB_IDX_AT_TOKEN && tokpos >= n_src) ok = false;
-        if (bun4 && ((d0 | d1) & 31u)) ok = false;              // fused un-filter works on whole 32-byte windows
-        const uint32_t ne = ush ? nbytes / (uint32_t)ush : 1u;  // bytes per plane
-        const uint32_t pj = ush ? d0 / ne : 0u;                 // my plane
-        if (ush && (pj >= (uint32_t)ush || d1 > (pj + 1u) * ne)) ok = false;   // a unit never straddles two planes
-        uint8_t *const udst = ush ? dst + (size_t)(d0 - pj * ne) * (uint32_t)ush + pj : dst + d0;
-        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
-        const uint32_t slen = s1 - s0, outlen = d1 - d0;
-        const uint8_t *g = src + s0;
-
-        // the whole unit lies inside one literal run (incompressible chunk): HBM -> HBM, no LDS
-        if (rem != HB_IDX_AT_TOKEN && rem >= outlen) {
-            const uint32_t left = rem - outlen;
-            bool fine = slen == outlen;
-            // a block that ends inside/after a literal run is accepted only if that token announces no match
-            // (UncompressBlock: si == len(src) && matchNibble == 0; oracle/blosc_oracle.c ob_lz4_decompress) -- else the serial decoder decides
-            if (last) fine = fine && left == 0 && (RFL((uint32_t)src[tokpos]) & 15u) == 0u; else fine = fine && rem1 == left && tok1 == tokpos;
-            if (!fine) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
-            if (ush) {                                          // wide loads (any alignment) into the image, then the strided stores
-                for (uint32_t i = lane * 16u; i < outlen; i += 1024u) {
-                    if (i + 16u <= outlen) *(u32x4 *)(s_out + i) = ld16u(g + i);
-                    else for (uint32_t r = i; r < outlen; r++) s_out[r] = g[r];
-                }
-                wave_sync();
-                for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
-                wave_sync();
-            }
-            else if (!bun4) wave_copy_g2g(dst + d0, g, outlen, lane);
-            else {
-                for (uint32_t w = lane; w < outlen / 32u; w += 64) {
-                    u32x4 oa, ob;
-                    bitshuffle4_window<true>(ld16u(g + 32u * w), ld16u(g + 32u * w + 16u), oa, ob);
-                    st16u(dst + d0 + 32u * w, oa);
-                    st16u(dst + d0 + 32u * w + 16u, ob);
-                }
-            }
-            continue;
-        }
-
-        // stage a window of the slice (all of it, for a dense unit); `at` = slice position the window has to start at.
-        // LDS byte k of s_in is global byte g - sh + a16 + k, a16 a multiple of 16: 16-byte aligned vector loads.
-        const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
-        uint32_t wlo = 0, staged = 0;                           // the window holds slice positions [wlo, staged)
-        int shw = 0;                                            // LDS index of slice position p = p + shw
-        auto stage = [&](const uint32_t at) __attribute__((always_inline)) {
-            wave_sync();
-            const uint32_t a16 = (sh + at) & ~15u;
-            const uint32_t avail = sh + slen - a16;
-            const uint32_t cnt = avail < DEC_IN_WIN ? avail : DEC_IN_WIN;
-            const u32x4 *ga = (const u32x4 *)(g - sh + a16);
-            const uint32_t nv = (cnt + 15u) >> 4;
-            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_in)[i] = ga[i];
-            wlo = a16 > sh ? a16 - sh : 0u;
-            staged = a16 + cnt - sh;
-            shw = (int)sh - (int)a16;
-            wave_sync();
-        };
-        stage(0u);
-        uint32_t tok = 0;
-        if (rem != HB_IDX_AT_TOKEN) tok = RFL((uint32_t)src[tokpos]);
-#define INB(i) s_in[(uint32_t)((int)(i) + shw)]              /* stream byte at slice position i (inside the window) */
-        uint32_t si = 0, di = 0;
-        bool at_token = false;       // state when the unit stops
-        bool done = false;
-
-        // State machine.  slow != 0: handle ONE sequence of any shape (length extensions of any size, bytes
-        // outside the staged window, end of the unit inside a literal run); slow == 2 starts at a token,
-        // slow == 1 inside the literal run (rem, tok) the unit begins in.  slow == 0: the window parser below.
-        int slow = 1;
-        uint32_t nq = 0;                                        // tokens queued in s_tq
-        if (rem == HB_IDX_AT_TOKEN) { rem = 0; slow = 0; }
-        while (ok && !done) {
-            if (slow) {
-                if (slow == 2) {
-                    if (si >= slen) { ok = false; break; }
-                    tokpos = s0 + si;
-                    tok = RFL((uint32_t)((si >= wlo && si < staged) ? INB(si) : g[si]));
-                    si++;
-                    rem = tok >> 4;
-                    if (rem == 15u && !dec_read_ext(s_in, shw, wlo, staged, g, slen, si, rem, lane)) { ok = false; break; }
-                }
-                slow = 0;
-                {   // literal phase
-                    const uint32_t take = min(rem, outlen - di);
-                    if (take > slen - si) { ok = false; break; }
-                    if (si >= wlo && si + take <= staged) { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = INB(si + i); }
-                    else { for (uint32_t i = lane; i < take; i += 64) s_out[di + i] = g[si + i]; }
-                    si += take; di += take; rem -= take;
-                }
-                if (rem > 0 || di == outlen) { at_token = false; done = true; break; }
-                // match phase
-                if (slen - si < 2) { ok = false; break; }             // also: block ends after literals -> serial decides
-                const uint32_t b0 = RFL((uint32_t)((si >= wlo && si < staged) ? INB(si) : g[si]));
-                const uint32_t b1 = RFL((uint32_t)((si + 1 >= wlo && si + 1 < staged) ? INB(si + 1) : g[si + 1]));
-                const uint32_t offset = b0 | (b1 << 8);
-                si += 2;
-                uint32_t mlen = (tok & 15u) + 4u;
-                if ((tok & 15u) == 15u && !dec_read_ext(s_in, shw, wlo, staged, g, slen, si, mlen, lane)) { ok = false; break; }
-                if (offset == 0 || offset > di || mlen > outlen - di) { ok = false; break; }
-                dec_match_copy(s_out, di, offset, mlen, lane);
-                di += mlen;
-                // peek: a next token with a multi-byte match extension would come straight back from the window parser
-                // (highly compressible units are a handful of such tokens): stay on this path
-                if (si >= wlo && si + 4u <= staged && di < outlen) {
-                    const uint32_t t2 = RFL((uint32_t)INB(si)), l2 = t2 >> 4;
-                    if (l2 < 15u && (t2 & 15u) == 15u) {
-                        const uint32_t op = si + 1u + l2;
-                        if (op + 3u <= staged && RFL((uint32_t)INB(op + 2u)) == 255u) slow = 2;
-                    }
-                }
-                continue;
-            }
-            if (nq == 0u && staged < slen && si + DEC_IN_MARGIN > staged) {     // move the window (queued tokens point into it)
-                stage(si);
-            }
-            const bool stop = dec_fill(s_in, (uint32_t)shw, staged, slen, si, nq, s_tq, lane);
-            bool rewound = false;
-            ok = dec_drain(s_in, shw, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
-            if (!ok) break;
-            if (rewound) { slow = 2; continue; }
-            if (stop) {
-                if (si == slen || di == outlen) { at_token = true; done = true; }
-                else if (staged < slen && si + DEC_IN_MARGIN > staged) continue;   // stopped at the end of the window, not at a complex token
-                else slow = 2;
-            }
-        }
-        // end-state check against the next entry
-        if (ok) {
-            ok = (si == slen) && (di == outlen);
-            if (last) ok = ok && (at_token || (rem == 0 && (tok & 15u) == 0u));   // ends after literals: the token must announce no match
-            else if (at_token) ok = ok && rem1 == HB_IDX_AT_TOKEN;
-            else ok = ok && rem1 == rem && tok1 == tokpos;
-        }
-        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); wave_sync(); continue; }
-        wave_sync();
-        if (bun4) {                                             // fused bit-unshuffle: every window in place
-            for (uint32_t w = lane; w < outlen / 32u; w += 64) {
-                u32x4 oa, ob;
-                bitshuffle4_window<true>(((const u32x4 *)s_out)[2 * w], ((const u32x4 *)s_out)[2 * w + 1], oa, ob);
-                ((u32x4 *)s_out)[2 * w] = oa;
-                ((u32x4 *)s_out)[2 * w + 1] = ob;
-            }
-            wave_sync();
-        }
-        // flush the chunk image
-        if (ush) {
-            for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
-        } else {
-            uint8_t *o = dst + d0;
-            uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);
-            if (head > outlen) head = outlen;
-            if ((uint32_t)lane < head) o[lane] = s_out[lane];
-            const uint32_t body = (outlen - head) >> 4;
-            if (head == 0) { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + i * 16u) = *(const u32x4 *)(s_out + i * 16u); }
-            else {
-                for (uint32_t i = lane; i < body; i += 64) {
-                    const uint8_t *q = s_out + head + i * 16u;
-                    u32x4 v;
-                    v.x = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-                    v.y = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
-                    v.z = (uint32_t)q[8] | ((uint32_t)q[9] << 8) | ((uint32_t)q[10] << 16) | ((uint32_t)q[11] << 24);
-                    v.w = (uint32_t)q[12] | ((uint32_t)q[13] << 8) | ((uint32_t)q[14] << 16) | ((uint32_t)q[15] << 24);
-                    *(u32x4 *)(o + head + i * 16u) = v;
-                }
-            }
-            const uint32_t done_b = head + body * 16u;
-            if (done_b + lane < outlen) o[done_b + lane] = s_out[done_b + lane];
-        }
-        wave_sync();
+        DecCtx c; c.src = src; c.n_src = n_src; c.dst = dst; c.ent = ent; c.plan = plan; c.nbytes = nbytes; c.nunits = nunits; c.bun4 = bun4; c.ush = ush;
+        dec_unit(c, u, s_in, s_out, s_tq, lane);
     }
+}
+
+// ---- batches of frames (hb_decompress_frames_batch_dev): the indexed decoder over the units of ALL frames of a batch ----
+// frame of every global unit (gaps between frames: no frame), and every frame's plan (one workgroup per frame)
+__global__ __launch_bounds__(64) void k_bt_dec_plan(const DecBatchFrame *__restrict__ bf, uint32_t nframes, uint32_t *__restrict__ unit_frame, uint32_t total_units) {
+    const uint32_t f = blockIdx.x;
+    const DecBatchFrame b = bf[f];
+    const uint32_t next = f + 1 < nframes ? bf[f + 1].unit0 : total_units;
+    for (uint32_t u = threadIdx.x; u < next - b.unit0; u += 64) unit_frame[b.unit0 + u] = u < b.nunits ? f : 0xFFFFFFFFu;
+    if (threadIdx.x == 0) {
+        dec_plan_check(b.preset == 1 ? b.index : nullptr, b.index_bytes, b.n_src, (uint64_t)b.nbytes, b.plan, b.result);
+        b.plan->pad[0] = 0; b.plan->pad[1] = 0;                      // (stream decoder's verdict and byte count, k_bt_dec_streams)
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES))) void k_dec_indexed_batch(const DecBatchFrame *__restrict__ bf,
+                                                    const uint32_t *__restrict__ unit_frame, uint32_t total_units) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_WIN + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    const int lane = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < total_units; it += gridDim.x) {
+        const uint32_t fid = unit_frame[it];
+        if (fid == 0xFFFFFFFFu) continue;
+        const DecBatchFrame &f = bf[fid];
+        if (f.plan->mode != DEC_INDEXED) continue;
+        DecCtx c; c.src = f.src; c.n_src = f.n_src; c.dst = f.dst; c.ent = f.index + HB_IDX_HDR_BYTES; c.plan = f.plan;
+        c.nbytes = f.plan->nbytes; c.nunits = f.plan->nunits; c.bun4 = f.bun4; c.ush = f.ush;
+        uint32_t u = it - f.unit0;
+        if (c.ush) {
+            // fused un-shuffle: as in k_dec_indexed -- the `ush` units of an element block get workgroup ids equal mod 8 (a frame's
+            // first unit is a multiple of 8 * ush in the flat space) and the plane rotates with the pass
+            const uint32_t T = (uint32_t)c.ush, nblk = c.nunits / T;
+            const uint32_t grp = u / (8u * T), r = u % (8u * T);
+            uint32_t b = grp * 8u + (r & 7u), j = ((r >> 3) + it / gridDim.x) % T;
+            if (grp * 8u + 8u > nblk) { const uint32_t k = u - grp * 8u * T, nb = nblk - grp * 8u; b = grp * 8u + k % nb; j = k / nb; }
+            u = j * nblk + b;
+        }
+        if (u >= c.nunits) continue;
+        dec_unit(c, u, s_in, s_out, s_tq, lane);
+    }
+}
+
+// unit0 of every frame (host): frames with a fused byte un-shuffle start at a multiple of 8 * typesize; returns the size of the flat space
+size_t hb_lz4_dec_batch_units(int nframes, const DecBatchFrame *h, uint32_t *unit0_out) {
+    uint64_t units = 0;
+    for (int k = 0; k < nframes; k++) {
+        const uint32_t g = h[k].ush ? 8u * (uint32_t)h[k].ush : 8u;
+        units = (units + g - 1) / g * g;
+        unit0_out[k] = (uint32_t)units;
+        units += h[k].nunits;
+    }
+    return (size_t)((units + 7) / 8 * 8);
+}
+
+int hb_launch_lz4_decode_batch_indexed(int nframes, const DecBatchFrame *d_bf, uint32_t *d_unit_frame, uint32_t total_units, int any_ush, hipStream_t s) {
+    hb_prof_begin("k_dec_plan", s);
+    hipLaunchKernelGGL(k_bt_dec_plan, dim3((unsigned)nframes), dim3(64), 0, s, d_bf, (uint32_t)nframes, d_unit_frame, total_units);
+    hb_prof_end(s);
+    if (total_units) {
+        unsigned grid = total_units < 256u * 256u ? total_units : 256u * 256u;
+        if (any_ush && total_units > 256u * 16u) {                    // as for one frame: `typesize` passes per workgroup in large batches
+            const unsigned gran = 32u;                               // a multiple of 8 * typesize for every fused typesize (2, 4): the groups of
+            unsigned g2 = total_units / (unsigned)any_ush / gran * gran;   // 8 * typesize work items of a frame must share their pass number
+            if (total_units > 256u * 64u && g2 < 256u * 64u) g2 = 256u * 64u;
+            if (g2 > 256u * 256u) g2 = 256u * 256u;
+            if (g2) grid = g2;
+        }
+        hb_prof_begin("k_dec_indexed", s);
+        hipLaunchKernelGGL(k_dec_indexed_batch, dim3(grid), dim3(64), 0, s, d_bf, (const uint32_t *)d_unit_frame, total_units);
+        hb_prof_end(s);
+    }
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@
 // bytes of the source read a second time by k_stitch; see DESIGN.md.
 #include "hb_lz4.h"
 #include <cstdlib>
+#include <vector>
 
 #ifndef HLOG_HC
 #define HLOG_HC 8
@@ -90,6 +91,23 @@ struct EncPlan {
     uint32_t nchunks;
     uint64_t index_off;      // byte offset of the index from the frame start (0: none / external buffer)
     uint64_t pad[4];
+};
+
+// ---- batches of frames in ONE set of launches (hb_compress_frames_batch_dev; SURVEY §8 f1 "frame batches") ----
+// Chunks are independent and the scan is per frame, so K frames are K segments of one flat chunk space: global chunk g belongs to
+// frame chunk_frame[g] and is that frame's chunk g - chunk0; scan tiles never span two frames (tile_frame[t]); descriptors, records
+// and tile summaries are indexed globally, positions and stream offsets stay frame-local.  The single-frame launches pass bf = NULL
+// and compile to what they were.
+struct BatchFrame {
+    const uint8_t *src;          // what the matcher reads: the filtered bytes, or the raw input when the filter is fused
+    uint8_t *dst;                // frame start
+    const uint8_t *memcpy_src;   // what a memcpy frame stores (NULL: the gated batch filter writes the payload)
+    hb_result *result;
+    EncPlan *plan;
+    uint64_t n;
+    uint32_t chunk0, nchunks;    // first global chunk / chunks of this frame
+    uint32_t tile0, ntiles;      // first global scan tile / tiles of this frame
+    uint32_t nblk, pad;          // fused byte shuffle: element blocks of the frame (nchunks = nblk * typesize)
 };
 
 // workspace layout
@@ -667,9 +685,10 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 // 32-byte window, shuffle.go:184-200) is applied to the chunk image in LDS -- filter fused, no filtered buffer in
 // HBM; the caller guarantees n % 32 == 0 and a 16-byte aligned src.
 template <int WAYS, int MODE>
-__global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, uint64_t n,
+__global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src_, uint64_t n_,
                                               ChunkDesc *__restrict__ desc, uint8_t *__restrict__ records,
-                                              uint32_t nchunks, int bits4, int keep_long, int accel) {
+                                              uint32_t nchunks, int bits4, int keep_long, int accel,
+                                              const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ chunk_frame) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
@@ -679,7 +698,14 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
     uint32_t *const s_st = (uint32_t *)(s_data + HB_CHUNK + 80);
     const int lane = threadIdx.x;
     for (uint32_t ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
-        const uint64_t start = (uint64_t)ck * HB_CHUNK;
+        const uint8_t *src = src_;
+        uint64_t n = n_, start = (uint64_t)ck * HB_CHUNK;
+        if (bf) {                                          // batch: global chunk ck is chunk ck - chunk0 of its frame
+            const uint32_t fid = chunk_frame[ck];
+            if (fid == 0xFFFFFFFFu) continue;              // (a gap between two frames: nobody's chunk)
+            const BatchFrame &f = bf[fid];
+            src = f.src; n = f.n; start = (uint64_t)(ck - f.chunk0) * HB_CHUNK;
+        }
         const int len = (int)((n - start) < HB_CHUNK ? (n - start) : HB_CHUNK);
         const uint8_t *g = src + start;
         const uint32_t sh = (uint32_t)((uintptr_t)g & 15u);
@@ -707,8 +733,9 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src, u
 // workgroup ids that are equal mod 8 (same XCD under round-robin placement: they share the L2 lines -- speed
 // only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
 template <int TS, int WAYS, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 6 : 4))) void k_match_fused(const uint8_t *__restrict__ src, ChunkDesc *__restrict__ desc,
-                                                    uint8_t *__restrict__ records, uint32_t nblk, uint32_t plane_mask, int accel) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 6 : 4))) void k_match_fused(const uint8_t *__restrict__ src_, ChunkDesc *__restrict__ desc,
+                                                    uint8_t *__restrict__ records, uint32_t nblk_, uint32_t plane_mask, int accel,
+                                                    const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ chunk_frame, uint32_t total_) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
@@ -717,12 +744,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
     uint32_t *const s_st = (uint32_t *)(s_data + HB_CHUNK + 80);
     const int lane = threadIdx.x;
-    const uint32_t total = nblk * TS;
-    for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+    const uint32_t total = bf ? total_ : nblk_ * TS;
+    for (uint32_t gi = blockIdx.x; gi < total; gi += gridDim.x) {
+        const uint8_t *src = src_;
+        uint32_t nblk = nblk_, i = gi, ck0 = 0;
+        if (bf) {                                          // batch: global work item gi is item gi - chunk0 of its frame (chunk0 is a
+            const uint32_t fid = chunk_frame[gi];          // multiple of 8 * TS there: the XCD of a block's planes is kept)
+            if (fid == 0xFFFFFFFFu) continue;              // (a gap between two frames: nobody's chunk)
+            const BatchFrame &f = bf[fid];
+            src = f.src; nblk = f.nblk; ck0 = f.chunk0; i = gi - ck0;
+        }
         // i -> (block b, plane j): within a group of 8 blocks, work item (j, b % 8) has index j * 8 + b % 8
         const uint32_t grp = i / (8u * TS), r = i % (8u * TS);
         // rotate the plane with the pass number: a workgroup's id fixes r, and planes differ a lot in cost
-        uint32_t b = grp * 8u + (r & 7u), j = ((r >> 3) + i / gridDim.x) % TS;
+        uint32_t b = grp * 8u + (r & 7u), j = ((r >> 3) + gi / gridDim.x) % TS;
         if (grp * 8u + 8u > nblk) {                        // ragged last group: plain (b, j) order
             const uint32_t k = i - grp * 8u * TS;
             const uint32_t nb = nblk - grp * 8u;
@@ -773,7 +808,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
                 }
             }
         }
-        const uint32_t ck = j * nblk + b;
+        const uint32_t ck = ck0 + j * nblk + b;
         match_chunk<WAYS, MODE>(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, accel, lane);
     }
 }
@@ -794,11 +829,16 @@ __device__ __forceinline__ void block_scan_agg(Agg *s, int t) {
 
 // per tile: aggregate of its chunks + position of its first match
 __global__ __launch_bounds__(256) void k_tiles(const ChunkDesc *__restrict__ desc, uint32_t nchunks,
-                                               Agg *__restrict__ tile_agg, uint32_t *__restrict__ tile_nf) {
+                                               Agg *__restrict__ tile_agg, uint32_t *__restrict__ tile_nf,
+                                               const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ tile_frame) {
     __shared__ Agg s[256];
     __shared__ uint32_t s_nf[256];
     const int t = threadIdx.x;
-    const uint32_t ck = blockIdx.x * HB_TILE_CHUNKS + t;
+    uint32_t ck = blockIdx.x * HB_TILE_CHUNKS + t;         // chunk inside its frame
+    if (bf) {                                              // batch: tile blockIdx.x is tile blockIdx.x - tile0 of its frame
+        const BatchFrame &f = bf[tile_frame[blockIdx.x]];
+        ck = (blockIdx.x - f.tile0) * HB_TILE_CHUNKS + t; nchunks = f.nchunks; desc += f.chunk0;
+    }
     Agg a = agg_identity();
     if (ck < nchunks) a = agg_of_chunk(desc[ck], ck * HB_CHUNK);
     s[t] = a;
@@ -819,12 +859,18 @@ struct FrameInfo { int frame, codec, shuffle, typesize; unsigned opts; };
 __global__ __launch_bounds__(256) void k_scan(const Agg *__restrict__ tile_agg, const uint32_t *__restrict__ tile_nf,
                                               Agg *__restrict__ tile_pre, uint32_t *__restrict__ tile_suf,
                                               uint32_t ntiles, uint32_t nchunks, uint64_t n, EncPlan *plan,
-                                              uint8_t *dst, FrameInfo fi, hb_result *result, int has_index) {
+                                              uint8_t *dst, FrameInfo fi, hb_result *result, int has_index,
+                                              const BatchFrame *__restrict__ bf) {
     __shared__ Agg s[256];
     __shared__ uint32_t s_nf[256];
     __shared__ Agg carry;
     __shared__ uint32_t carry_nf;
     const int t = threadIdx.x;
+    if (bf) {                                              // batch: one workgroup per frame, over that frame's tiles
+        const BatchFrame &f = bf[blockIdx.x];
+        tile_agg += f.tile0; tile_nf += f.tile0; tile_pre += f.tile0; tile_suf += f.tile0;
+        ntiles = f.ntiles; nchunks = f.nchunks; n = f.n; plan = f.plan; dst = f.dst; result = f.result;
+    }
     if (t == 0) { carry = agg_identity(); carry_nf = 0xFFFFFFFFu; }
     __syncthreads();
     for (uint32_t base = 0; base < ntiles; base += 256) {       // forward
@@ -905,13 +951,20 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
         const Agg *__restrict__ tile_pre, const uint32_t *__restrict__ tile_suf, const EncPlan *__restrict__ plan,
         uint32_t nchunks, uint64_t n, uint8_t *__restrict__ out /* block start */,
         uint8_t *__restrict__ index_base_ext, uint8_t *__restrict__ frame_base, const uint8_t *__restrict__ memcpy_src,
-        int lit_from_records) {
+        int lit_from_records, const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ tile_frame) {
     __shared__ Agg s[256];
     __shared__ uint32_t s_nf[256];
     __shared__ ChunkDesc s_desc[256];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     constexpr int NW = STITCH_THREADS / 64;
-    const uint32_t ck0 = blockIdx.x * HB_TILE_CHUNKS;
+    uint32_t tile = blockIdx.x;                                       // tile inside its frame
+    if (bf) {                                                         // batch: everything frame-local from here on
+        const BatchFrame &f = bf[tile_frame[blockIdx.x]];
+        tile = blockIdx.x - f.tile0;
+        desc += f.chunk0; records += (size_t)f.chunk0 * HB_RSTRIDE; src = f.src; tile_pre += f.tile0; tile_suf += f.tile0;
+        plan = f.plan; nchunks = f.nchunks; n = f.n; out = f.dst + HB_HEADER_SIZE; frame_base = f.dst; memcpy_src = f.memcpy_src;
+    }
+    const uint32_t ck0 = tile * HB_TILE_CHUNKS;
     const uint32_t cnt = min(HB_TILE_CHUNKS, nchunks - ck0);
 
     if (plan->use_memcpy) {                                           // blosc.go:343-345: payload = (filtered) input
@@ -939,8 +992,8 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
         if (t < 256) s_nf[t] = min(x, y);
         __syncthreads();
     }
-    const Agg tpre = tile_pre[blockIdx.x];                            // (uniform address: scalar loads)
-    const uint32_t tsuf = tile_suf[blockIdx.x];
+    const Agg tpre = tile_pre[tile];                                  // (uniform address: scalar loads)
+    const uint32_t tsuf = tile_suf[tile];
     // values read from LDS are wave-uniform here but arrive in vector registers: move them to scalar ones, or every
     // address computation and copy loop below runs on the vector side under exec masks
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))     /* the builtin is int -> int: no sign extension later */
@@ -1136,8 +1189,9 @@ static inline void enc_policy(const hb_enc_args &a, int &ways, int &accel) {
     else if (a.codec == HB_LZ4 && a.frame) accel = level <= 3 ? 128 : (level <= 6 ? 64 : 0);
 }
 
-#define HB_LAUNCH_FUSED(TS, W, SN) hipLaunchKernelGGL((k_match_fused<TS, W, SN>), dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask(), accel)
-static void launch_match_fused(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, uint8_t *records, uint32_t nblk, hipStream_t s) {
+#define HB_LAUNCH_FUSED(TS, W, SN) hipLaunchKernelGGL((k_match_fused<TS, W, SN>), dim3(grid), dim3(64), 0, s, a.src, desc, records, nblk, hb_dbg_plane_mask(), accel, bf, chunk_frame, total_items)
+static void launch_match_fused(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, uint8_t *records, uint32_t nblk, hipStream_t s,
+                               const BatchFrame *bf = nullptr, const uint32_t *chunk_frame = nullptr, uint32_t total_items = 0) {
     int ways, accel;
     enc_policy(a, ways, accel);
     const bool sn = a.codec == HB_SNAPPY;
@@ -1147,8 +1201,9 @@ static void launch_match_fused(const hb_enc_args &a, unsigned grid, ChunkDesc *d
     default: if (sn) HB_LAUNCH_FUSED(8, 1, true); else if (ways == 1) HB_LAUNCH_FUSED(8, 1, false); else if (ways == 2) HB_LAUNCH_FUSED(8, 2, false); else HB_LAUNCH_FUSED(8, 4, false); break;
     }
 }
-#define HB_LAUNCH_MATCH(W, SN) hipLaunchKernelGGL((k_match<W, SN>), dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, nchunks, a.fused_bits, keep_long, accel)
-static void launch_match(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, uint8_t *records, uint32_t nchunks, hipStream_t s) {
+#define HB_LAUNCH_MATCH(W, SN) hipLaunchKernelGGL((k_match<W, SN>), dim3(grid), dim3(64), 0, s, a.src, (uint64_t)a.n, desc, records, nchunks, a.fused_bits, keep_long, accel, bf, chunk_frame)
+static void launch_match(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, uint8_t *records, uint32_t nchunks, hipStream_t s,
+                         const BatchFrame *bf = nullptr, const uint32_t *chunk_frame = nullptr) {
     int ways, accel;
     enc_policy(a, ways, accel);
     // byte-shuffled frames keep the fused kernels' table policy, fused or not (identical frames either way)
@@ -1162,7 +1217,7 @@ static void launch_match(const hb_enc_args &a, unsigned grid, ChunkDesc *desc, u
 // every HB_CHUNK bytes of src become an LZ4 block of their own (hb_cblosc.hip): records + descriptors only, nothing is stitched
 void hb_launch_match_selfcontained(const uint8_t *src, size_t n, void *desc, uint8_t *records, uint32_t nchunks, int accel, hipStream_t s) {
     const unsigned grid = nchunks < 256u * 256u ? nchunks : 256u * 256u;
-    hipLaunchKernelGGL((k_match<1, 2>), dim3(grid), dim3(64), 0, s, src, (uint64_t)n, (ChunkDesc *)desc, records, nchunks, 0, 0, accel);
+    hipLaunchKernelGGL((k_match<1, 2>), dim3(grid), dim3(64), 0, s, src, (uint64_t)n, (ChunkDesc *)desc, records, nchunks, 0, 0, accel, (const BatchFrame *)nullptr, (const uint32_t *)nullptr);
 }
 
 // the same with the byte shuffle fused (typesize 2 / 4 / 8): chunk (plane j, element block b) lands at index j * nblk + b
@@ -1170,9 +1225,9 @@ bool hb_launch_match_fused_selfcontained(const uint8_t *src, int typesize, void 
     const uint64_t items = (uint64_t)nblk * (uint64_t)typesize;
     const unsigned grid = (unsigned)(items < 256u * 256u ? items : 256u * 256u);
     switch (typesize) {
-    case 2: hipLaunchKernelGGL((k_match_fused<2, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel); return true;
-    case 4: hipLaunchKernelGGL((k_match_fused<4, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel); return true;
-    case 8: hipLaunchKernelGGL((k_match_fused<8, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel); return true;
+    case 2: hipLaunchKernelGGL((k_match_fused<2, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel, (const BatchFrame *)nullptr, (const uint32_t *)nullptr, 0u); return true;
+    case 4: hipLaunchKernelGGL((k_match_fused<4, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel, (const BatchFrame *)nullptr, (const uint32_t *)nullptr, 0u); return true;
+    case 8: hipLaunchKernelGGL((k_match_fused<8, 1, 2>), dim3(grid), dim3(64), 0, s, src, (ChunkDesc *)desc, records, nblk, 0xFFFFFFFFu, accel, (const BatchFrame *)nullptr, (const uint32_t *)nullptr, 0u); return true;
     default: return false;
     }
 }
@@ -1217,7 +1272,7 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
             hb_prof_end(s);
         } else {
             hb_prof_begin("k_tiles", s);
-            hipLaunchKernelGGL(k_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg, tile_nf);
+            hipLaunchKernelGGL(k_tiles, dim3(L.ntiles), dim3(256), 0, s, desc, L.nchunks, tile_agg, tile_nf, (const BatchFrame *)nullptr, (const uint32_t *)nullptr);
             hb_prof_end(s);
         }
     }
@@ -1237,7 +1292,7 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
     }
     hb_prof_begin("k_scan", s);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, s, tile_agg, tile_nf, tile_pre, tile_suf, L.ntiles, L.nchunks,
-                       (uint64_t)a.n, plan, a.dst, fi, a.result, has_index);
+                       (uint64_t)a.n, plan, a.dst, fi, a.result, has_index, (const BatchFrame *)nullptr);
     hb_prof_end(s);
     if ((a.fused_ts || a.fused_bits) && !a.memcpy_src) {
         // memcpy fallback of a fused frame (blosc.go:342-345 with the filtered payload): the shuffled bytes were never
@@ -1249,9 +1304,167 @@ int hb_launch_lz4_encode(const hb_enc_args &a, hipStream_t s) {
         hb_prof_begin("k_stitch", s);
         hipLaunchKernelGGL(k_stitch, dim3(L.ntiles), dim3(STITCH_THREADS), 0, s, desc, records, a.src, tile_pre, tile_suf,
                            plan, L.nchunks, (uint64_t)a.n, out, a.frame ? (uint8_t *)nullptr : a.index,
-                           a.frame ? a.dst : (uint8_t *)nullptr, a.memcpy_src, (a.fused_ts || a.fused_bits) ? 1 : 0);
+                           a.frame ? a.dst : (uint8_t *)nullptr, a.memcpy_src, (a.fused_ts || a.fused_bits) ? 1 : 0,
+                           (const BatchFrame *)nullptr, (const uint32_t *)nullptr);
         hb_prof_end(s);
     }
+    HB_HIP_TRY(hipGetLastError());
+    return HB_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// batches: K frames, one set of launches (hb_compress_frames_batch_dev)
+// ----------------------------------------------------------------------------------------------
+struct EncBatchLayout {
+    size_t frames, plans, jobs, chunk_frame, tile_frame, desc, tile_agg, tile_nf, tile_pre, tile_suf, records, filtered, total;
+    uint32_t total_chunks, total_tiles;
+};
+// granule of a frame's first global chunk: with the fused byte shuffle the planes of an element block sit 8 work items apart and must
+// keep their workgroup id mod 8 (XCD), so every frame starts at a multiple of 8 * typesize (the gap chunks belong to no frame)
+static inline uint32_t batch_granule(bool fused_ts, int typesize) { return fused_ts ? 8u * (uint32_t)typesize : 1u; }
+
+static EncBatchLayout enc_batch_layout(int nframes, const size_t *n, uint32_t granule, bool need_filtered) {
+    EncBatchLayout L{};
+    uint64_t chunks = 0, tiles = 0, fbytes = 0;
+    for (int k = 0; k < nframes; k++) {
+        const uint64_t c = (n[k] + HB_CHUNK - 1) / HB_CHUNK;
+        chunks = (chunks + granule - 1) / granule * granule + c;
+        tiles += (c + HB_TILE_CHUNKS - 1) / HB_TILE_CHUNKS;
+        fbytes += (n[k] + 255) & ~(size_t)255;
+    }
+    L.total_chunks = (uint32_t)chunks; L.total_tiles = (uint32_t)tiles;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    L.frames = take((size_t)nframes * sizeof(BatchFrame));
+    L.plans = take((size_t)nframes * sizeof(EncPlan));
+    L.jobs = take((size_t)nframes * sizeof(hb_filter_job) * 2);
+    L.chunk_frame = take((size_t)chunks * 4 + 4);
+    L.tile_frame = take((size_t)tiles * 4 + 4);
+    L.desc = take((size_t)chunks * sizeof(ChunkDesc));
+    L.tile_agg = take((size_t)tiles * sizeof(Agg));
+    L.tile_nf = take((size_t)tiles * 4);
+    L.tile_pre = take((size_t)tiles * sizeof(Agg));
+    L.tile_suf = take((size_t)tiles * 4);
+    L.records = take((size_t)chunks * HB_RSTRIDE + 256);
+    L.filtered = take(need_filtered ? fbytes + 256 : 0);
+    L.total = o;
+    return L;
+}
+// (sized for the larger of the two shapes a batch can take: gaps for the fused shuffle, a filtered copy otherwise)
+size_t hb_lz4_enc_batch_workspace(int nframes, const size_t *n, int typesize) {
+    if (nframes <= 0 || !n) return 256;
+    const size_t a = enc_batch_layout(nframes, n, batch_granule(true, typesize > 0 && typesize <= 8 ? typesize : 8), false).total;
+    const size_t b = enc_batch_layout(nframes, n, 1u, true).total;
+    return a > b ? a : b;
+}
+
+// frame of every global chunk and of every scan tile (gap chunks: no frame)
+__global__ __launch_bounds__(64) void k_bt_map(const BatchFrame *__restrict__ bf, uint32_t nframes, uint32_t *__restrict__ chunk_frame, uint32_t *__restrict__ tile_frame,
+                                               uint32_t total_chunks) {
+    const uint32_t f = blockIdx.x;
+    const BatchFrame b = bf[f];
+    const uint32_t next = f + 1 < nframes ? bf[f + 1].chunk0 : total_chunks;
+    for (uint32_t c = threadIdx.x; c < next - b.chunk0; c += 64) chunk_frame[b.chunk0 + c] = c < b.nchunks ? f : 0xFFFFFFFFu;
+    for (uint32_t t = threadIdx.x; t < b.ntiles; t += 64) tile_frame[b.tile0 + t] = f;
+}
+
+int hb_launch_lz4_encode_batch(int nframes, const hb_batch_frame *fr, int codec, int level, int shuffle, int typesize, unsigned opts,
+                               uint8_t *work, size_t work_bytes, hipStream_t s) {
+    if (nframes <= 0) return HB_OK;
+    if (codec != HB_LZ4 && codec != HB_LZ4HC) return HB_ERR_INVALID_CODEC;
+    const bool filt = (shuffle == HB_SHUFFLE || shuffle == HB_BITSHUFFLE) && typesize > 1;          // blosc.go:329-333
+    // the filter is fused into the matcher when EVERY frame of the batch allows it (same rules as hb_compress_frame_dev); else all
+    // frames take the two-pass path: one batched filter launch into a filtered copy, then the plain matcher
+    bool fused = filt && shuffle == HB_SHUFFLE && (typesize == 2 || typesize == 4 || typesize == 8) && !(opts & HB_OPT_NO_FUSION);
+    bool fused_bits = filt && shuffle == HB_BITSHUFFLE && typesize == 4 && !(opts & HB_OPT_NO_FUSION);
+    size_t max_n = 0;
+    std::vector<size_t> ns((size_t)nframes);
+    for (int k = 0; k < nframes; k++) {
+        ns[(size_t)k] = fr[k].n;
+        max_n = fr[k].n > max_n ? fr[k].n : max_n;
+        if (fused && fr[k].n % ((size_t)typesize * HB_CHUNK) != 0) fused = false;
+        if (fused_bits && (fr[k].n % 32 != 0 || ((uintptr_t)fr[k].src & 15u))) fused_bits = false;
+        // (a frame shorter than one element is not filtered at all, shuffle.go:17-19: the two-pass path points the matcher at its source)
+    }
+    const uint32_t granule = batch_granule(fused, typesize);
+    const bool need_filtered = filt && !fused && !fused_bits;
+    const EncBatchLayout L = enc_batch_layout(nframes, ns.data(), granule, need_filtered);
+    if (work_bytes < L.total) return HB_ERR_SHORT_BUFFER;
+    BatchFrame *d_bf = (BatchFrame *)(work + L.frames);
+    EncPlan *d_plans = (EncPlan *)(work + L.plans);
+    hb_filter_job *d_jobs = (hb_filter_job *)(work + L.jobs);
+    uint32_t *chunk_frame = (uint32_t *)(work + L.chunk_frame), *tile_frame = (uint32_t *)(work + L.tile_frame);
+    ChunkDesc *desc = (ChunkDesc *)(work + L.desc);
+    Agg *tile_agg = (Agg *)(work + L.tile_agg), *tile_pre = (Agg *)(work + L.tile_pre);
+    uint32_t *tile_nf = (uint32_t *)(work + L.tile_nf), *tile_suf = (uint32_t *)(work + L.tile_suf);
+    uint8_t *records = work + L.records, *filtered = work + L.filtered;
+
+    std::vector<BatchFrame> h((size_t)nframes);
+    std::vector<hb_filter_job> jobs((size_t)nframes * 2);          // [0, K): the filter pass; [K, 2K): the gated memcpy-fallback shuffle of fused frames
+    uint64_t chunks = 0, tiles = 0, foff = 0;
+    for (int k = 0; k < nframes; k++) {
+        const size_t n = fr[k].n;
+        const uint32_t c = (uint32_t)((n + HB_CHUNK - 1) / HB_CHUNK);
+        chunks = (chunks + granule - 1) / granule * granule;
+        BatchFrame &b = h[(size_t)k];
+        const bool f_filt = filt && n >= (size_t)typesize;
+        const uint8_t *in = fr[k].src;
+        if (need_filtered && f_filt) in = filtered + foff;
+        b.src = (fused || fused_bits) ? fr[k].src : in;
+        b.dst = fr[k].dst;
+        b.memcpy_src = (opts & HB_OPT_REFERENCE_MEMCPY) ? fr[k].src : ((fused || fused_bits) ? nullptr : in);
+        b.result = fr[k].result;
+        b.plan = d_plans + k;
+        b.n = n;
+        b.chunk0 = (uint32_t)chunks; b.nchunks = c;
+        b.tile0 = (uint32_t)tiles; b.ntiles = (c + HB_TILE_CHUNKS - 1) / HB_TILE_CHUNKS;
+        b.nblk = fused ? c / (uint32_t)typesize : 0u; b.pad = 0;
+        jobs[(size_t)k] = hb_filter_job{filtered + foff, fr[k].src, (need_filtered && f_filt) ? (uint64_t)n : 0ull, nullptr};
+        jobs[(size_t)(nframes + k)] = hb_filter_job{fr[k].dst + HB_HEADER_SIZE, fr[k].src, ((fused || fused_bits) && !b.memcpy_src) ? (uint64_t)n : 0ull, &(d_plans + k)->use_memcpy};
+        chunks += c; tiles += b.ntiles; foff += (n + 255) & ~(size_t)255;
+    }
+    // (pageable host memory: the runtime stages these copies before the call returns, so the vectors may go out of scope)
+    HB_HIP_TRY(hipMemcpyAsync(d_bf, h.data(), h.size() * sizeof(BatchFrame), hipMemcpyHostToDevice, s));
+    HB_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(hb_filter_job), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_bt_map, dim3((unsigned)nframes), dim3(64), 0, s, d_bf, (uint32_t)nframes, chunk_frame, tile_frame, L.total_chunks);
+    if (need_filtered) {
+        hb_prof_begin(shuffle == HB_SHUFFLE ? "filter_shuffle" : "filter_bitshuffle", s);
+        const int rc = hb_launch_filter_batch(shuffle == HB_SHUFFLE ? HB_OP_SHUFFLE : HB_OP_BITSHUFFLE, d_jobs, nframes, max_n, typesize, s);
+        hb_prof_end(s);
+        if (rc) return rc;
+    }
+    hb_enc_args a{};                                                 // what the launch helpers read: policy and fusion only
+    a.frame = 1; a.codec = codec; a.shuffle = shuffle; a.typesize = typesize; a.opts = opts; a.level = level;
+    a.fused_ts = fused ? typesize : 0; a.fused_bits = fused_bits ? 4 : 0;
+    FrameInfo fi{1, codec, shuffle, typesize, opts};
+    const int has_index = (opts & HB_OPT_INDEX_TRAILER) ? 1 : 0;
+    unsigned grid = L.total_chunks < 256u * 256u ? L.total_chunks : 256u * 256u;
+    if (fused && L.total_chunks > 256u * 16u) {                      // as for one frame: `typesize` passes per workgroup where the batch is large
+        grid = L.total_chunks / (unsigned)typesize / granule * granule;   // enough (the plane rotates with the pass: every workgroup meets every plane)
+        if (L.total_chunks > 256u * 64u && grid < 256u * 64u) grid = 256u * 64u;
+        if (grid > 256u * 256u) grid = 256u * 256u;
+        if (grid == 0) grid = L.total_chunks;
+    }
+    hb_prof_begin(fused ? "k_match_fused" : "k_match", s);
+    if (fused) launch_match_fused(a, grid, desc, records, 0u, s, d_bf, chunk_frame, L.total_chunks);
+    else launch_match(a, grid, desc, records, L.total_chunks, s, d_bf, chunk_frame);
+    hb_prof_end(s);
+    hb_prof_begin("k_tiles", s);
+    hipLaunchKernelGGL(k_tiles, dim3(L.total_tiles), dim3(256), 0, s, desc, 0u, tile_agg, tile_nf, (const BatchFrame *)d_bf, (const uint32_t *)tile_frame);
+    hb_prof_end(s);
+    hb_prof_begin("k_scan", s);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)nframes), dim3(256), 0, s, tile_agg, tile_nf, tile_pre, tile_suf, 0u, 0u, (uint64_t)0, (EncPlan *)nullptr,
+                       (uint8_t *)nullptr, fi, (hb_result *)nullptr, has_index, (const BatchFrame *)d_bf);
+    hb_prof_end(s);
+    if (fused || fused_bits) {                                       // memcpy frames of a fused batch: the payload is filtered in place, frames that compressed leave at once
+        const int rc = hb_launch_filter_batch(fused_bits ? HB_OP_BITSHUFFLE : HB_OP_SHUFFLE, d_jobs + nframes, nframes, max_n, typesize, s);
+        if (rc) return rc;
+    }
+    hb_prof_begin("k_stitch", s);
+    hipLaunchKernelGGL(k_stitch, dim3(L.total_tiles), dim3(STITCH_THREADS), 0, s, desc, records, (const uint8_t *)nullptr, tile_pre, tile_suf,
+                       (const EncPlan *)nullptr, 0u, (uint64_t)0, (uint8_t *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, (const uint8_t *)nullptr,
+                       (fused || fused_bits) ? 1 : 0, (const BatchFrame *)d_bf, (const uint32_t *)tile_frame);
+    hb_prof_end(s);
     HB_HIP_TRY(hipGetLastError());
     return HB_OK;
 }

@@ -96,6 +96,8 @@ EXPORTS = [
     "hb_compress_frame_dev", "hb_decompress_frame_dev", "hb_compress_frames_multi", "hb_decompress_frames_multi",
     "hb_profile_enable", "hb_profile_count", "hb_profile_get", "hb_last_result_flags",
     "hb_decompress_frame_dev_hdr", "hb_cblosc_parse_header", "hb_cblosc_decompress", "hb_cblosc_compress", "hb_cblosc_bound", "hb_cblosc_compress_workspace", "hb_cblosc_compress_dev", "hb_cblosc_decompress_workspace", "hb_cblosc_decompress_dev",
+    "hb_compress_frames_batch_workspace", "hb_compress_frames_batch_dev", "hb_frames_batch_headers_dev",
+    "hb_decompress_frames_batch_workspace", "hb_decompress_frames_batch_dev", "hb_compress_frames_batch", "hb_decompress_frames_batch",
     "hb_queue_create", "hb_queue_create_ex", "hb_queue_destroy", "hb_queue_compress", "hb_queue_decompress", "hb_queue_wait",
 ]
 
@@ -156,6 +158,13 @@ def lib():
             "hb_cblosc_bound": (sz, [sz, i32]), "hb_cblosc_compress_workspace": (sz, [sz, i32, i32]),
             "hb_cblosc_compress_dev": (i32, [vp, sz, vp, sz, i32, i32, vp, sz, vp, vp]), "hb_cblosc_decompress": (i64, [vp, sz, vp, sz, i32]),
             "hb_cblosc_decompress_workspace": (sz, [sz, sz, sz]), "hb_cblosc_decompress_dev": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, vp]),
+            "hb_compress_frames_batch_workspace": (sz, [i32, vp, i32]),
+            "hb_compress_frames_batch_dev": (i32, [i32, vp, vp, vp, vp, i32, i32, i32, i32, u32, vp, sz, vp, vp]),
+            "hb_frames_batch_headers_dev": (i32, [i32, vp, vp, vp, vp, vp, sz, vp]),
+            "hb_decompress_frames_batch_workspace": (sz, [i32, vp]),
+            "hb_decompress_frames_batch_dev": (i32, [i32, vp, vp, vp, vp, vp, i32, vp, sz, vp, vp]),
+            "hb_compress_frames_batch": (i32, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, u32, i32]),
+            "hb_decompress_frames_batch": (i32, [i32, vp, vp, vp, vp, vp, i32, i32]),
             "hb_queue_create": (vp, [i32, i32, sz]), "hb_queue_create_ex": (vp, [i32, i32, sz, ctypes.c_uint]), "hb_queue_destroy": (None, [vp]),
             "hb_queue_compress": (i64, [vp, vp, sz, vp, sz, i32, i32, i32, i32, u32]),
             "hb_queue_decompress": (i64, [vp, vp, sz, vp, sz, i32]),
@@ -480,3 +489,51 @@ def CBloscCompress(data, shuffle=1, typesize=4):
     out = ctypes.create_string_buffer(cap)
     rc = _check(lib().hb_cblosc_compress(p, n, ctypes.cast(out, ctypes.c_void_p), cap, shuffle, typesize, device))
     return out.raw[:rc]
+
+
+# ---------------------------------------------------------------------------------------------
+# batches of small frames in one set of launches (hb_compress_frames_batch / hb_decompress_frames_batch): the i-th result is what
+# Compress / Decompress would have returned for the i-th input -- a frame, or the reference's sentinel error (returned, not raised)
+# ---------------------------------------------------------------------------------------------
+def CompressBatch(datas, codec=LZ4, level=5, shuffle=Shuffle1, typesize=4, opts=0, dev=None):
+    n = len(datas)
+    if n == 0:
+        return []
+    L = lib()
+    keep = [_buf(d) for d in datas]
+    caps = [L.hb_frame_bound(k[1]) for k in keep]
+    outs = [(ctypes.c_char * c)() for c in caps]
+    vp, sz, i64 = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n
+    srcs = vp(*[k[0].value for k in keep])
+    dsts = vp(*[ctypes.addressof(o) for o in outs])
+    rcs = i64()
+    _check(L.hb_compress_frames_batch(n, srcs, sz(*[k[1] for k in keep]), dsts, sz(*caps), rcs, int(codec), int(level), int(shuffle), int(typesize),
+                                      int(opts), device if dev is None else dev))
+    res = []
+    for i in range(n):
+        res.append(bytes(outs[i][: rcs[i]]) if rcs[i] >= 0 else _BY_CODE.get(int(rcs[i]), HipBloscError)(f"code {rcs[i]}"))
+    return res
+
+
+def DecompressBatch(frames, typesize=0, dev=None):
+    n = len(frames)
+    if n == 0:
+        return []
+    L = lib()
+    keep = [_buf(f) for f in frames]
+    caps = []
+    for f in frames:
+        try:
+            caps.append(max(ParseHeader(bytes(f[:16])).NBytesOrig, 1))
+        except BloscError:
+            caps.append(1)
+    outs = [(ctypes.c_char * c)() for c in caps]
+    vp, sz, i64 = ctypes.c_void_p * n, ctypes.c_size_t * n, ctypes.c_int64 * n
+    srcs = vp(*[k[0].value for k in keep])
+    dsts = vp(*[ctypes.addressof(o) for o in outs])
+    rcs = i64()
+    _check(L.hb_decompress_frames_batch(n, srcs, sz(*[k[1] for k in keep]), dsts, sz(*caps), rcs, int(typesize), device if dev is None else dev))
+    res = []
+    for i in range(n):
+        res.append(bytes(outs[i][: rcs[i]]) if rcs[i] >= 0 else _BY_CODE.get(int(rcs[i]), HipBloscError)(f"code {rcs[i]}"))
+    return res

@@ -194,6 +194,41 @@ int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *
 int hb_decompress_frames_multi(int nframes, const void *const *frame, const size_t *n,
                                void *const *dst, const size_t *cap, int64_t *rc, int typesize_override);
 
+/* ---- batches of SMALL frames in one set of launches (SURVEY.md §8 f1 "frame batches") ----
+ * The reference's own benchmark is a 100 000-byte frame (blosc_test.go:363-413): one such frame is 25 chunks of work, far too little
+ * for four kernel launches of its own.  These entry points put `nframes` independent Compress / Decompress calls (blosc.go:257-303,
+ * one frame each, same Options for all) through ONE set of launches: the chunks and index units of all frames form one flat work
+ * space, the per-frame scan / header / memcpy rule (blosc.go:342-371) is a segmented scan.  Every frame is byte-identical to what
+ * hb_compress_frame_dev would have written for it.  d_src / d_frame / d_dst are HOST arrays of DEVICE pointers; asynchronous on `stream`;
+ * d_results: `nframes` hb_result records in device (or pinned) memory, one per frame, as the one-frame entry points fill them.
+ * Codecs LZ4 and LZ4HC (HB_ERR_INVALID_CODEC otherwise: Snappy / ZSTD frames go one call per frame).  An argument error of any frame
+ * refuses the whole compress batch before anything is launched (the return value says which error). */
+size_t hb_compress_frames_batch_workspace(int nframes, const size_t *n, int typesize);
+int hb_compress_frames_batch_dev(int nframes, const void *const *d_src, const size_t *n, void *const *d_frame, const size_t *cap,
+                                 int codec, int level, int shuffle, int typesize, unsigned opts,
+                                 void *d_work, size_t work_bytes, hb_result *d_results, void *stream);
+/* headers of device-resident frames: one gather + ONE D2H + one stream synchronisation for the whole batch (hb_decompress_frame_dev pays
+ * one per frame); hdrs[k] = ParseHeader (blosc.go:165-185) of frame k where rc[k] == HB_OK.  d_scratch: >= 32 * nframes + 256 bytes. */
+int hb_frames_batch_headers_dev(int nframes, const void *const *d_frame, const size_t *n, hb_header *hdrs, int *rc,
+                                void *d_scratch, size_t scratch_bytes, void *stream);
+/* hdrs: the parsed headers (host memory: a Go caller has them, its frames came from host memory; else hb_frames_batch_headers_dev).
+ * Frames that carry the restart index (HB_OPT_INDEX_TRAILER) are decoded chunk-parallel, all frames' units in one launch; frames without
+ * one -- the default frame shape, and frames of other writers (the reference) -- by ONE wavefront per frame, all frames at once.  A frame
+ * the host can refuse from its header (blosc.go:385-390, :403-407; destination too small) gets its error in d_results[k] and does not
+ * disturb the others; everything else reports as hb_decompress_frame_dev does (blosc.go:377-434).  no stream synchronisation. */
+size_t hb_decompress_frames_batch_workspace(int nframes, const hb_header *hdrs);
+int hb_decompress_frames_batch_dev(int nframes, const hb_header *hdrs, const void *const *d_frame, const size_t *n,
+                                   void *const *d_dst, const size_t *cap, int typesize_override,
+                                   void *d_work, size_t work_bytes, hb_result *d_results, void *stream);
+
+/* the same with HOST pointers (what a Go caller with many small []byte has): stages through cached device buffers, per-frame outcome in
+ * rc[k] exactly as hb_compress_frame / hb_decompress_frame would return it (frames the batch does not carry -- other codecs, argument
+ * errors -- are answered by those entry points, one call each).  Returns HB_OK unless the arguments as a whole are unusable. */
+int hb_compress_frames_batch(int nframes, const void *const *src, const size_t *n, void *const *dst, const size_t *cap, int64_t *rc,
+                             int codec, int level, int shuffle, int typesize, unsigned opts, int device);
+int hb_decompress_frames_batch(int nframes, const void *const *frame, const size_t *n, void *const *dst, const size_t *cap, int64_t *rc,
+                               int typesize_override, int device);
+
 /* ---- pipelined host API: frames in flight on their own streams ----
  * The one-call entry points above move H2D -> kernels -> D2H back to back, so a caller sees n / (t_h2d + t_k + t_d2h).
  * A queue keeps `depth` frames in flight, each on its own stream with its own device buffers: the upload of frame k+1

@@ -1,0 +1,122 @@
+"""GPU parity for SURVEY §8 row f1 "frame batches": many small frames through ONE set of launches.
+
+The reference's own benchmark is a 100 000-byte frame (blosc_test.go:363-413); hb_compress_frames_batch / hb_decompress_frames_batch put
+K independent Compress / Decompress calls (blosc.go:257-303) through the kernels of one frame, flattened.  Contract checked here: every
+frame of a batch is BYTE-IDENTICAL to what the one-frame entry point writes for the same input and options, every frame decodes through
+the oracle (the restated reference decoder) to its input, the batch decoder returns what the one-frame decoder returns -- bytes and error
+identities -- for frames with and without the restart index, frames the oracle (= reference-shaped encoder) wrote, memcpy frames,
+damaged frames; one bad frame never disturbs its neighbours.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(O, rng):
+    xs = []
+    xs.append(bytes(i % 256 for i in range(100000)))                              # the reference's benchmark frame, blosc_test.go:363-371
+    xs.append(O.synth(O.D_RAMP, 25000).tobytes())                                 # f32 i*0.1, 100 000 B (blosc_test.go:109-111 shape)
+    for k in range(6):
+        xs.append(O.synth(O.D_F32, 16384 * (k + 1), frame=k).tobytes())           # whole element blocks: the fused shuffle path
+    xs.append(O.synth(O.D_F32, 30001, frame=7).tobytes())                         # ragged: two-pass path
+    xs.append(O.synth(O.D_I32, 8 * 4096 + 24, frame=8).tobytes())
+    xs.append(rng.integers(0, 256, 70000, dtype=np.uint8).tobytes())              # incompressible: memcpy frame (blosc.go:342-345)
+    xs.append(bytes(5000))                                                        # zeros
+    xs.append(b"abc")                                                             # shorter than an element
+    xs.append(bytes(range(13)))
+    xs.append(O.synth(O.D_F64, 4096 * 3, frame=9).tobytes())
+    return xs
+
+
+@pytest.mark.parametrize("shuffle,ts", [(0, 1), (1, 4), (2, 4), (1, 8), (1, 2), (2, 8), (1, 3)])
+@pytest.mark.parametrize("opts_name", ["default", "index"])
+def test_batch_frames_are_the_one_call_frames(hb, O, shuffle, ts, opts_name):
+    rng = np.random.default_rng(100 * shuffle + ts)
+    xs = _inputs(O, rng)
+    opts = hb.OPT_INDEX_TRAILER if opts_name == "index" else 0
+    frames = hb.CompressBatch(xs, hb.LZ4, 5, shuffle, ts, opts=opts)
+    assert len(frames) == len(xs)
+    for i, (x, f) in enumerate(zip(xs, frames)):
+        assert isinstance(f, bytes), (i, f)
+        one = hb.Compress(x, hb.LZ4, 5, shuffle, ts, opts=opts)
+        assert f == one, f"frame {i} ({len(x)} B): the batch wrote a different frame than the one-frame entry point"
+        h = hb.GetInfo(f)
+        assert h.NBytesOrig == len(x) and h.TypeSize == ts
+        if not (h.IsMemcpy() and shuffle and len(x) >= ts):                       # (memcpy + filter: the reference's own defect)
+            assert O.decompress_frame(np.frombuffer(f[:h.NBytesComp], np.uint8)).tobytes() == x, i
+    back = hb.DecompressBatch(frames)
+    for i, (x, b) in enumerate(zip(xs, back)):
+        assert b == x, f"frame {i}: batch decode differs"
+
+
+def test_all_fusable_batch_and_hc(hb, O):
+    # every frame whole element blocks: the filter is fused into the matcher for the whole batch; LZ4HC levels ride the same launches
+    xs = [O.synth(O.D_F32, 16384 * (1 + k % 5), frame=k).tobytes() for k in range(40)]
+    for codec, level in ((hb.LZ4, 5), (hb.LZ4, 1), (hb.LZ4HC, 5), (hb.LZ4HC, 9)):
+        for opts in (0, hb.OPT_INDEX_TRAILER):
+            frames = hb.CompressBatch(xs, codec, level, hb.Shuffle1, 4, opts=opts)
+            for k, (x, f) in enumerate(zip(xs, frames)):
+                assert f == hb.Compress(x, codec, level, hb.Shuffle1, 4, opts=opts), (codec, level, opts, k)
+            assert O.decompress_frame(np.frombuffer(frames[3], np.uint8)).tobytes() == xs[3]
+            assert hb.DecompressBatch(frames) == xs
+
+
+def test_batch_decodes_what_others_wrote_and_reports_like_the_one_call_decoder(hb, O):
+    rng = np.random.default_rng(5)
+    xs = _inputs(O, rng)
+    frames = []
+    for i, x in enumerate(xs):
+        a = np.frombuffer(x, np.uint8)
+        # frames of the oracle's reference-shaped encoder (one block, 64 KiB window, no index): Shuffle1 ts 4, NoShuffle, BitShuffle ts 8
+        frames.append(O.compress_frame(a, shuffle=(1, 0, 2)[i % 3], typesize=(4, 1, 8)[i % 3]).tobytes())
+    # damaged frames in between: what the reference's tests damage (blosc_test.go:593-611 payload xor, codec_test.go:60-79 nbytes, cbytes)
+    good = hb.Compress(xs[2], hb.LZ4, 5, hb.Shuffle1, 4, opts=hb.OPT_INDEX_TRAILER)
+    bad1 = bytearray(good); bad1[16:200] = bytes(b ^ 0xFF for b in bad1[16:200])
+    bad2 = bytearray(good); bad2[4:8] = (len(xs[2]) * 2).to_bytes(4, "little"); bad2[8:12] = bad2[4:8]
+    bad3 = bytearray(good); bad3[12:16] = (len(good) + 100).to_bytes(4, "little")
+    bad4 = bytearray(good); bad4[0] = 7
+    bad5 = bytes([2, 1, 0, 4]) + (1000).to_bytes(4, "little") * 2 + (20).to_bytes(4, "little") + b"\xff\xff\xff\xff"   # codec_test.go:276-284
+    frames[3:3] = [bytes(bad1), bytes(bad2)]
+    frames += [bytes(bad3), bytes(bad4), bad5, good[:10], good]
+    got = hb.DecompressBatch(frames)
+    assert len(got) == len(frames)
+    for i, f in enumerate(frames):
+        try:
+            want = hb.Decompress(f)
+        except hb.BloscError as e:
+            want = type(e)
+        if isinstance(want, type):
+            assert isinstance(got[i], want), (i, got[i], want)
+            try:                                                                  # ... and the oracle (the restated reference) agrees on the class
+                O.decompress_frame(np.frombuffer(f, np.uint8))
+                assert False, i
+            except Exception:                                                     # noqa: BLE001
+                pass
+        else:
+            assert got[i] == want, i
+
+
+def test_large_batch_of_the_reference_benchmark_frame(hb, O):
+    # 512 x the 100 000-byte byte(i % 256) frame of blosc_test.go:363-371 + 512 x a float frame: every frame equal to the one-call frame
+    a = bytes(i % 256 for i in range(100000))
+    b = O.synth(O.D_F32, 25000, frame=3).tobytes()
+    xs = [a, b] * 512
+    fa, fb = hb.Compress(a, hb.LZ4, 5, hb.Shuffle1, 4), hb.Compress(b, hb.LZ4, 5, hb.Shuffle1, 4)
+    frames = hb.CompressBatch(xs, hb.LZ4, 5, hb.Shuffle1, 4)
+    assert all(f == (fa, fb)[i & 1] for i, f in enumerate(frames))
+    assert O.decompress_frame(np.frombuffer(fa, np.uint8)).tobytes() == a and O.decompress_frame(np.frombuffer(fb, np.uint8)).tobytes() == b
+    back = hb.DecompressBatch(frames)
+    assert all(x == (a, b)[i & 1] for i, x in enumerate(back))
+
+
+def test_batch_argument_errors(hb, O):
+    # empty input is ErrInvalidData for that frame only (blosc.go:269-271), like the one-call API
+    xs = [b"hello world, hello world, hello world", b"", O.synth(O.D_F32, 5000).tobytes()]
+    fr = hb.CompressBatch(xs, hb.LZ4, 5, hb.Shuffle1, 4)
+    assert isinstance(fr[1], hb.ErrInvalidData) and fr[0] == hb.Compress(xs[0], hb.LZ4, 5, hb.Shuffle1, 4) and fr[2] == hb.Compress(xs[2], hb.LZ4, 5, hb.Shuffle1, 4)
+    # Snappy frames are not carried by the batch kernels: answered by the one-frame entry point, same bytes
+    sn = hb.CompressBatch([xs[0], xs[2]], hb.Snappy, 5, hb.Shuffle1, 4)
+    assert sn == [hb.Compress(xs[0], hb.Snappy, 5, hb.Shuffle1, 4), hb.Compress(xs[2], hb.Snappy, 5, hb.Shuffle1, 4)]
+    assert hb.DecompressBatch(sn + [fr[0]]) == [xs[0], xs[2], xs[0]]
+    assert hb.CompressBatch([]) == [] and hb.DecompressBatch([]) == []
