@@ -30,6 +30,7 @@
 // Everything malformed (offset 0, offset before the block, lengths running off the stream, output beyond cap) only raises
 // plan->fail; k_dec_serial then decodes the block and reports what lz4.UncompressBlock would report.
 #include "hb_lz4_region.h"
+#include <cstdlib>
 
 size_t hb_lz4_region_workspace(size_t n_out) { return rg_layout(n_out).total + ((hb_lz4_index_bound(n_out) + 255) & ~(size_t)255); }
 // blocks below 256 KiB stay with the single wavefront (a dozen launches cost more than they save)
@@ -566,8 +567,123 @@ __device__ __forceinline__ void rg_emit(uint8_t *ents, uint64_t U, uint32_t s_of
     uint32_t *e = (uint32_t *)(ents + (U / HB_CHUNK) * HB_IDX_ENTRY);
     e[0] = s_off; e[1] = (uint32_t)U; e[2] = lit_rem; e[3] = tok_off;
 }
+// Round 3: the walk below costs a wavefront about a microsecond per 64 stream bytes (~0.5 ms for a 34 KiB region, 1.1 ms per GiB for
+// the launch) only to find the unit boundaries inside the region.  The first parse left a record of where it was at the start of each
+// of 128 buckets of the region's stream range ({position, output so far}: `traces`), and from reg[r].pad0 on that record lies on the
+// final chain.  k_rg_index_fast: one wavefront per region, one LANE per recorded token: lane k walks the tokens from its record to the
+// next one (a bucket: <= 512 stream bytes, staged in LDS for all lanes at once) and writes the entry of every unit boundary it comes
+// by -- the same three cases as the wave walk (at a token, inside a literal run, inside a match = not chunk-local).  What the records do
+// not cover -- the region's head up to its first usable record (the stretch the first parse needed to fall onto the chain), regions
+// whose record is not on the chain at all -- is left to k_rg_index: done[r] = where its walk may stop (0: walk everything).
+// Same entries either way (tests/test_gpu_codec.py, test_gpu_foreign.py at 16 MiB - 1 GiB; A/B: HIPBLOSC_DEBUG_SLOW_INDEX=1).
+#define RG_IDX_BUF 16384u         // staged stream bytes per round
+__global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
+                                                      const uint2 *__restrict__ traces, uint8_t *__restrict__ index, uint32_t *__restrict__ done) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[RG_IDX_BUF + 128];
+    __shared__ uint2 s_tr[RG_BUCKETS + 1];
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    if (lane == 0) done[r] = 0u;
+    if (!plan->ok || plan->fail || r >= plan->nreg) return;
+    const uint64_t N = plan->total;
+    uint8_t *ents = index + HB_IDX_HDR_BYTES;
+    const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit), outlen = RFL(reg[r].outlen), pad0 = RFL(reg[r].pad0);
+    if (outlen == 0u || start >= exitp) { if (lane == 0) done[r] = 0xFFFFFFFFu; return; }
+    const uint32_t adj = outlen - RFL(reg[r].outlen0);                  // output position (from `entry`) of a recorded token = its recorded value + adj
+    const uint64_t opos = reg[r].opos;
+    // the record is usable where it lies on the final chain: from pad0 on, and only when the recorded parse ends where the chain's does
+    // (the rule of hb_lz4_sym.hip k_sy_units)
+    if (pad0 == RG_INVALID || RFL(reg[r].exit0) != exitp) return;
+    if (opos / HB_CHUNK == (opos + outlen - 1) / HB_CHUNK && (opos & (HB_CHUNK - 1)) != 0) { if (lane == 0) done[r] = 0xFFFFFFFFu; return; }   // no boundary in here
+    // the usable records, compacted in stream order: { position, output position from `entry` }
+    uint32_t nu = 0;
+    {
+        const uint2 *tr = traces + (size_t)r * RG_TRACE + RG_DENSE;
+        for (uint32_t b0 = 0; b0 < RG_BUCKETS; b0 += 64) {
+            uint2 t = tr[b0 + lane];
+            const bool ok = t.x != RG_INVALID && t.x >= pad0 && t.x > start && t.x < exitp;
+            const unsigned long long m = hb_ballot(ok);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (ok) { t.y += adj; s_tr[nu + rank] = t; }
+            nu += (uint32_t)__builtin_popcountll(m);
+        }
+    }
+    if (nu == 0u) return;
+    if (lane == 0) { uint2 e; e.x = exitp; e.y = outlen; s_tr[nu] = e; }
+    wave_sync();
+    const uint32_t headend = s_tr[0].x;
+    bool bad = false;
+    uint32_t k0 = 0;
+    while (k0 < nu) {
+        // this round: records [k0, k1) -- at most 64, and no more stream than the buffer holds (a record's walk reads <= 64 bytes past its end)
+        const uint32_t a = s_tr[k0].x;
+        uint32_t k1 = k0 + 1;
+        while (k1 < nu && k1 - k0 < 64u && s_tr[k1 + 1].x - a + 64u <= RG_IDX_BUF) k1++;
+        const uint32_t bend = s_tr[k1].x;                               // first position behind this round's segments
+        if (bend - a + 64u > RG_IDX_BUF) { bad = true; break; }        // a single bucket larger than the buffer: not this kernel's case
+        const uint32_t sh = a & 15u, nv = (sh + (bend - a) + 64u + 15u) >> 4;
+        wave_sync();
+        for (uint32_t i = lane; i < nv; i += 256u) {                    // 4 independent 16-byte loads per lane and step
+            u32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t vi = i + 64u * (uint32_t)j;
+                const uint64_t at = (uint64_t)(a - sh) + 16ull * vi;
+                v[j].x = v[j].y = v[j].z = v[j].w = 0u;
+                if (vi < nv) { if (at + 16u <= n_src) v[j] = ld16u(src + at); else for (uint32_t b = 0; b < 16u; b++) if (at + b < n_src) ((uint8_t *)&v[j])[b] = src[at + b]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const uint32_t vi = i + 64u * (uint32_t)j; if (vi < nv) ((u32x4 *)s_buf)[vi] = v[j]; }
+        }
+        wave_sync();
+        const uint32_t k = k0 + (uint32_t)lane;
+        if (k < k1) {
+            const uint32_t send = s_tr[k + 1].x;                        // my segment: tokens that START in [s_tr[k].x, send)
+            uint64_t q = s_tr[k].x;                                     // absolute stream position
+            uint64_t d0 = s_tr[k].y;                                    // output position (from `entry`) of the token at q
+            const uint32_t lim = bend + 64u;                            // staged up to here
+            auto byte = [&](uint64_t at) __attribute__((always_inline)) -> uint32_t { return (uint32_t)s_buf[sh + (uint32_t)(at - a)]; };
+            while (q < send && !bad) {
+                if (q + 24u > lim) { bad = true; break; }
+                const uint32_t tp = (uint32_t)q;
+                const uint32_t tok = byte(q++);
+                uint64_t ll = tok >> 4;
+                if (ll == 15u) { for (;;) { if (q >= n_src || q >= lim) { bad = true; break; } const uint32_t x = byte(q++); ll += x; if (x != 255u) break; } }
+                if (bad) break;
+                const uint64_t ls = q;
+                if (ll > n_src - ls) { bad = true; break; }
+                q += ll;
+                uint64_t ml = 0;
+                if (q != n_src) {
+                    if (n_src - q < 2) { bad = true; break; }
+                    if (q < send || (tok & 15u) == 15u) {               // (the match length of a segment's last token matters only for the inside-a-match test)
+                        if (q + 24u > lim) { bad = true; break; }
+                    }
+                    q += 2; ml = (tok & 15u) + 4u;
+                    if ((tok & 15u) == 15u) { for (;;) { if (q >= n_src || q >= lim) { bad = true; break; } const uint32_t x = byte(q++); ml += x; if (x != 255u) break; } }
+                    if (bad) break;
+                }
+                // unit boundaries of this sequence: at its token, inside its literal run (any number of them), never in its match
+                const uint64_t g0 = opos + d0;                          // absolute output position of the sequence
+                uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+                if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
+                for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
+                if (U < g0 + ll + ml && U < N) { bad = true; break; }   // a unit boundary inside a match: the block was not written chunk-locally
+                d0 += ll + ml;
+            }
+            if (!bad && k + 1 <= nu && (q != send || (uint32_t)d0 != s_tr[k + 1].y)) bad = true;     // my walk must land on the next record exactly
+        }
+        if (hb_ballot(bad)) break;
+        k0 = k1;
+    }
+    // anything odd: the wave walk does the whole region again, with the machinery the other decoders share (it also decides what a
+    // boundary inside a match means for the frame)
+    if (hb_ballot(bad)) { if (lane == 0) done[r] = 6u; return; }
+    if (lane == 0) done[r] = headend;                                   // the head [entry, first usable record) is still to do
+}
+
 __global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
-                                                 uint8_t *__restrict__ index) {
+                                                 const uint32_t *__restrict__ done, uint8_t *__restrict__ index) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     if (!plan->ok || plan->fail) return;
@@ -578,6 +694,10 @@ __global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src
     for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
         const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit);
         if (RFL(reg[r].outlen) == 0u || start >= exitp) continue;
+        // k_rg_index_fast: 0 = nothing done, 0xFFFFFFFF = all of this region's entries written, else only the head [entry, that position) is left
+        const uint32_t dn = done ? RFL(done[r]) : 0u;
+        if (dn == 0xFFFFFFFFu) continue;
+        const uint32_t walk_end = dn >= 16u ? dn : exitp;
         uint64_t out = reg[r].opos;
         // unit boundaries of a sequence: at its token, inside its literal run (any number of them), never in its match
         auto batch = [&](uint32_t cnt, uint32_t tp, uint32_t ls, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t lp) __attribute__((always_inline)) -> bool {
@@ -607,8 +727,14 @@ __global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src
             out += (uint64_t)lit + mlen;
             return true;
         };
-        if (!rg_walk(src, n_src, start, exitp, s_win, s_tq, lane, batch, single) && lane == 0) atomicExch(&plan->fail, 1u);
+#ifdef RG_DEBUG_TIMES
+        const uint64_t t0 = wall_clock64();
+#endif
+        if (!rg_walk(src, n_src, start, walk_end, s_win, s_tq, lane, batch, single) && lane == 0) atomicExch(&plan->fail, 1u);
         wave_sync();
+#ifdef RG_DEBUG_TIMES
+        if (lane == 0 && done) ((uint32_t *)done)[r] = 0x80000000u | (uint32_t)((wall_clock64() - t0) / 100);      // microseconds (100 MHz clock)
+#endif
     }
 }
 
@@ -659,7 +785,10 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     hipLaunchKernelGGL(k_rg_scan, dim3(1), dim3(1024), 0, s, plan, reg, (uint64_t)a.n, (uint64_t)a.cap);
     hb_prof_end(s);
     hb_prof_begin("k_rg_index", s);
-    hipLaunchKernelGGL(k_rg_index, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, idx);
+    static const bool slow_index = [] { const char *e = getenv("HIPBLOSC_DEBUG_SLOW_INDEX"); return e && *e && *e != '0'; }();   // A/B: the wave-parallel walk only
+    uint32_t *done = (uint32_t *)(w + L.pmax);                          // (k_rg_pmax / k_rg_fix are through with it)
+    if (!slow_index) hipLaunchKernelGGL(k_rg_index_fast, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, (const uint2 *)traces, idx, done);
+    hipLaunchKernelGGL(k_rg_index, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, slow_index ? (const uint32_t *)nullptr : (const uint32_t *)done, idx);
     hipLaunchKernelGGL(k_rg_index_head, dim3(1), dim3(1), 0, s, plan, idx, (uint64_t)a.n);
     hb_prof_end(s);
     HB_HIP_TRY(hipGetLastError());
