@@ -571,15 +571,36 @@ __device__ __forceinline__ void rg_emit(uint8_t *ents, uint64_t U, uint32_t s_of
 // the launch) only to find the unit boundaries inside the region.  The first parse left a record of where it was at the start of each
 // of 128 buckets of the region's stream range ({position, output so far}: `traces`), and from reg[r].pad0 on that record lies on the
 // final chain.  k_rg_index_fast: one wavefront per region, one LANE per recorded token: lane k walks the tokens from its record to the
-// next one (a bucket: <= 512 stream bytes, staged in LDS for all lanes at once) and writes the entry of every unit boundary it comes
+// next one (a bucket: <= 512 stream bytes of token starts) and writes the entry of every unit boundary it comes
 // by -- the same three cases as the wave walk (at a token, inside a literal run, inside a match = not chunk-local).  What the records do
 // not cover -- the region's head up to its first usable record (the stretch the first parse needed to fall onto the chain), regions
 // whose record is not on the chain at all -- is left to k_rg_index: done[r] = where its walk may stop (0: walk everything).
 // Same entries either way (tests/test_gpu_codec.py, test_gpu_foreign.py at 16 MiB - 1 GiB; A/B: HIPBLOSC_DEBUG_SLOW_INDEX=1).
-#define RG_IDX_BUF 16384u         // staged stream bytes per round
+// (Measured on the way, 1 GiB D-f32: with the buckets staged in 16 KiB of LDS per wave the launch took 1.02 ms -- 9 waves per CU, each
+// lane's byte-serial walk ~140 us per region: no better than the wave walk at 32 waves per CU.  The lanes read the stream straight
+// from memory instead, a dword per access -- token + first extension bytes, offset + first extension bytes -- at full occupancy.)
+__device__ __forceinline__ uint32_t rg_rd4(const uint8_t *__restrict__ src, const uint64_t n_src, const uint64_t at) {
+    if (at + 4u <= n_src) return ld4u(src + at);
+    uint32_t w = 0;
+    for (uint32_t b = 0; b < 4u; b++) if (at + b < n_src) w |= (uint32_t)src[at + b] << (8u * b);
+    return w;
+}
+// a length extension (bytes 255 ... 255 r) at stream position q: adds it to len, moves q behind it; false: runs off the stream / absurd
+__device__ __forceinline__ bool rg_ext(const uint8_t *__restrict__ src, const uint64_t n_src, uint64_t &q, uint64_t &len) {
+    for (int k = 0; k < 4096; k++) {
+        if (q >= n_src) return false;
+        const uint32_t w = rg_rd4(src, n_src, q);
+        if (w == 0xFFFFFFFFu && q + 4u <= n_src) { len += 1020u; q += 4u; continue; }
+        const uint32_t nff = (uint32_t)__builtin_ctz(~w) >> 3;
+        if (q + nff >= n_src) return false;
+        len += 255u * nff + ((w >> (8u * nff)) & 255u);
+        q += nff + 1u;
+        return true;
+    }
+    return false;
+}
 __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
                                                       const uint2 *__restrict__ traces, uint8_t *__restrict__ index, uint32_t *__restrict__ done) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[RG_IDX_BUF + 128];
     __shared__ uint2 s_tr[RG_BUCKETS + 1];
     const int lane = threadIdx.x;
     const uint32_t r = blockIdx.x;
@@ -613,68 +634,47 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
     wave_sync();
     const uint32_t headend = s_tr[0].x;
     bool bad = false;
-    uint32_t k0 = 0;
-    while (k0 < nu) {
-        // this round: records [k0, k1) -- at most 64, and no more stream than the buffer holds (a record's walk reads <= 64 bytes past its end)
-        const uint32_t a = s_tr[k0].x;
-        uint32_t k1 = k0 + 1;
-        while (k1 < nu && k1 - k0 < 64u && s_tr[k1 + 1].x - a + 64u <= RG_IDX_BUF) k1++;
-        const uint32_t bend = s_tr[k1].x;                               // first position behind this round's segments
-        if (bend - a + 64u > RG_IDX_BUF) { bad = true; break; }        // a single bucket larger than the buffer: not this kernel's case
-        const uint32_t sh = a & 15u, nv = (sh + (bend - a) + 64u + 15u) >> 4;
-        wave_sync();
-        for (uint32_t i = lane; i < nv; i += 256u) {                    // 4 independent 16-byte loads per lane and step
-            u32x4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t vi = i + 64u * (uint32_t)j;
-                const uint64_t at = (uint64_t)(a - sh) + 16ull * vi;
-                v[j].x = v[j].y = v[j].z = v[j].w = 0u;
-                if (vi < nv) { if (at + 16u <= n_src) v[j] = ld16u(src + at); else for (uint32_t b = 0; b < 16u; b++) if (at + b < n_src) ((uint8_t *)&v[j])[b] = src[at + b]; }
+    for (uint32_t k = (uint32_t)lane; k < nu; k += 64u) {
+        const uint32_t send = s_tr[k + 1].x;                            // my segment: the tokens that START in [s_tr[k].x, send)
+        uint64_t q = s_tr[k].x;                                         // stream position
+        uint64_t d0 = s_tr[k].y;                                        // output position (from `entry`) of the token at q
+        for (uint32_t steps = 0; q < send; steps++) {
+            if (steps > 1024u) { bad = true; break; }                   // (a bucket holds <= 512 stream bytes of token starts: cannot happen on the chain)
+            const uint32_t tp = (uint32_t)q;
+            const uint32_t w = rg_rd4(src, n_src, q);
+            const uint32_t tok = w & 255u;
+            uint64_t ll = tok >> 4;
+            q++;
+            if (ll == 15u) {
+                const uint32_t b1 = (w >> 8) & 255u;
+                if (b1 != 255u && q < n_src) { ll += b1; q++; }
+                else if (!rg_ext(src, n_src, q, ll)) { bad = true; break; }
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { const uint32_t vi = i + 64u * (uint32_t)j; if (vi < nv) ((u32x4 *)s_buf)[vi] = v[j]; }
-        }
-        wave_sync();
-        const uint32_t k = k0 + (uint32_t)lane;
-        if (k < k1) {
-            const uint32_t send = s_tr[k + 1].x;                        // my segment: tokens that START in [s_tr[k].x, send)
-            uint64_t q = s_tr[k].x;                                     // absolute stream position
-            uint64_t d0 = s_tr[k].y;                                    // output position (from `entry`) of the token at q
-            const uint32_t lim = bend + 64u;                            // staged up to here
-            auto byte = [&](uint64_t at) __attribute__((always_inline)) -> uint32_t { return (uint32_t)s_buf[sh + (uint32_t)(at - a)]; };
-            while (q < send && !bad) {
-                if (q + 24u > lim) { bad = true; break; }
-                const uint32_t tp = (uint32_t)q;
-                const uint32_t tok = byte(q++);
-                uint64_t ll = tok >> 4;
-                if (ll == 15u) { for (;;) { if (q >= n_src || q >= lim) { bad = true; break; } const uint32_t x = byte(q++); ll += x; if (x != 255u) break; } }
-                if (bad) break;
-                const uint64_t ls = q;
-                if (ll > n_src - ls) { bad = true; break; }
-                q += ll;
-                uint64_t ml = 0;
-                if (q != n_src) {
-                    if (n_src - q < 2) { bad = true; break; }
-                    if (q < send || (tok & 15u) == 15u) {               // (the match length of a segment's last token matters only for the inside-a-match test)
-                        if (q + 24u > lim) { bad = true; break; }
-                    }
-                    q += 2; ml = (tok & 15u) + 4u;
-                    if ((tok & 15u) == 15u) { for (;;) { if (q >= n_src || q >= lim) { bad = true; break; } const uint32_t x = byte(q++); ml += x; if (x != 255u) break; } }
-                    if (bad) break;
-                }
-                // unit boundaries of this sequence: at its token, inside its literal run (any number of them), never in its match
-                const uint64_t g0 = opos + d0;                          // absolute output position of the sequence
-                uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
-                if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
-                for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
-                if (U < g0 + ll + ml && U < N) { bad = true; break; }   // a unit boundary inside a match: the block was not written chunk-locally
-                d0 += ll + ml;
+            const uint64_t ls = q;
+            if (ll > n_src - ls) { bad = true; break; }
+            q += ll;
+            uint64_t ml = 0;
+            if (q != n_src) {
+                if (n_src - q < 2) { bad = true; break; }
+                ml = (tok & 15u) + 4u;
+                if ((tok & 15u) == 15u) {
+                    const uint32_t x = rg_rd4(src, n_src, q);
+                    const uint32_t b2 = (x >> 16) & 255u;
+                    q += 2;
+                    if (b2 != 255u && q < n_src) { ml += b2; q++; }
+                    else if (!rg_ext(src, n_src, q, ml)) { bad = true; break; }
+                } else q += 2;
             }
-            if (!bad && k + 1 <= nu && (q != send || (uint32_t)d0 != s_tr[k + 1].y)) bad = true;     // my walk must land on the next record exactly
+            // unit boundaries of this sequence: at its token, inside its literal run (any number of them), never in its match
+            const uint64_t g0 = opos + d0;                              // absolute output position of the sequence
+            uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+            if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
+            for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
+            if (U < g0 + ll + ml && U < N) { bad = true; break; }       // a unit boundary inside a match: the block was not written chunk-locally
+            d0 += ll + ml;
         }
-        if (hb_ballot(bad)) break;
-        k0 = k1;
+        if (!bad && (q != send || (uint32_t)d0 != s_tr[k + 1].y)) bad = true;           // my walk must land on the next record exactly
+        if (bad) break;
     }
     // anything odd: the wave walk does the whole region again, with the machinery the other decoders share (it also decides what a
     // boundary inside a match means for the frame)
