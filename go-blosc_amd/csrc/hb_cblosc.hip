@@ -460,6 +460,11 @@ static CbEncLayout cbe_layout(size_t n, int shuffle, int typesize) {
     return L;
 }
 
+// launch shape of the 16-byte-per-lane filter kernel (k_cb_bitshuffle4_fast): every thread gets ONE work item, no grid-stride passes (round 3,
+// tools/lab/filter_lab.hip: streaming kernels on this chip want the dispatcher to deal out the work: 0.76 -> 0.55 ms).  The byte-gathering
+// kernels (k_cb_unshuffle & co.) are the opposite case: the same change took them from 0.61 to 0.88 ms -- they keep their 2048 workgroups.
+static inline unsigned cb_grid(uint64_t items) { const uint64_t g = (items + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > (1u << 24) ? (1u << 24) : g)); }
+
 extern "C" {
 
 // header fields of a C-Blosc-1 frame (host side); HB_OK or the error a malformed header gets
@@ -546,10 +551,17 @@ int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, s
     if (filtered) {
         hb_prof_begin("k_cb_unfilter", s);
         if (unshuf)
-            hipLaunchKernelGGL(k_cb_unshuffle, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nbytes, blocksize, ts);
+            {
+            // whole blocks of whole 1024-element tiles: the tile kernels of hb_filters.hip, block by block (6 TB/s instead of the 3.5 of the
+            // byte-gathering kernel); a last, shorter block -- or any other shape -- the plain way
+            const uint32_t nfull = nbytes / blocksize, tail = nbytes - nfull * blocksize;
+            if (hb_launch_shuffle_blocks(true, (uint8_t *)d_dst, staged, nfull, blocksize, (int)ts, s)) {
+                if (tail) hipLaunchKernelGGL(k_cb_unshuffle, dim3(64), dim3(256), 0, s, (uint8_t *)d_dst + (size_t)nfull * blocksize, staged + (size_t)nfull * blocksize, tail, blocksize, ts);
+            } else hipLaunchKernelGGL(k_cb_unshuffle, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nbytes, blocksize, ts);
+        }
         else if (ts == 4u && blocksize % 512u == 0u && nbytes >= blocksize) {       // whole blocks the fast way, a last shorter one the plain way
             const uint32_t nfull = nbytes / blocksize, tail = nbytes - nfull * blocksize;
-            hipLaunchKernelGGL(k_cb_bitshuffle4_fast<false>, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nfull, blocksize);
+            hipLaunchKernelGGL(k_cb_bitshuffle4_fast<false>, dim3(cb_grid((uint64_t)nfull * (blocksize / 128u))), dim3(256), 0, s, (uint8_t *)d_dst, staged, nfull, blocksize);
             if (tail) hipLaunchKernelGGL(k_cb_bitunshuffle, dim3(64), dim3(256), 0, s, (uint8_t *)d_dst + (size_t)nfull * blocksize, staged + (size_t)nfull * blocksize, tail, blocksize, ts);
         } else
             hipLaunchKernelGGL(k_cb_bitunshuffle, dim3(2048), dim3(256), 0, s, (uint8_t *)d_dst, staged, nbytes, blocksize, ts);
@@ -600,9 +612,13 @@ int hb_cblosc_compress_dev(const void *d_src, size_t n, void *d_frame, size_t ca
     if (fuse) {
         if (tail) hipLaunchKernelGGL(k_cb_shuffle, dim3(64), dim3(256), 0, s, filtered + (size_t)L.nfull * L.blocksize, (const uint8_t *)d_src + (size_t)L.nfull * L.blocksize, tail, L.blocksize, (uint32_t)typesize);
     } else if (unshuf || bits) {
-        if (unshuf) hipLaunchKernelGGL(k_cb_shuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
+        if (unshuf) {
+            if (hb_launch_shuffle_blocks(false, filtered, (const uint8_t *)d_src, L.nfull, L.blocksize, typesize, s)) {
+                if (tail) hipLaunchKernelGGL(k_cb_shuffle, dim3(64), dim3(256), 0, s, filtered + (size_t)L.nfull * L.blocksize, (const uint8_t *)d_src + (size_t)L.nfull * L.blocksize, tail, L.blocksize, (uint32_t)typesize);
+            } else hipLaunchKernelGGL(k_cb_shuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
+        }
         else if (typesize == 4 && L.blocksize % 512u == 0u && L.nfull) {
-            hipLaunchKernelGGL(k_cb_bitshuffle4_fast<true>, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, L.nfull, L.blocksize);
+            hipLaunchKernelGGL(k_cb_bitshuffle4_fast<true>, dim3(cb_grid((uint64_t)L.nfull * (L.blocksize / 128u))), dim3(256), 0, s, filtered, (const uint8_t *)d_src, L.nfull, L.blocksize);
             if (tail) hipLaunchKernelGGL(k_cb_bitshuffle, dim3(64), dim3(256), 0, s, filtered + (size_t)L.nfull * L.blocksize, (const uint8_t *)d_src + (size_t)L.nfull * L.blocksize, tail, L.blocksize, (uint32_t)typesize);
         } else hipLaunchKernelGGL(k_cb_bitshuffle, dim3(2048), dim3(256), 0, s, filtered, (const uint8_t *)d_src, (uint32_t)n, L.blocksize, (uint32_t)typesize);
         fsrc = filtered;

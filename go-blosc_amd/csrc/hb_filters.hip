@@ -346,6 +346,32 @@ static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n
     return HB_OK;
 }
 
+// ---- the byte shuffle applied to every `blocksize`-byte block of a buffer on its own (C-Blosc-1 frames filter per block, hb_cblosc.hip):
+// tile blockIdx.x = (block, tile inside the block).  Whole blocks of whole tiles only; the caller does a last, shorter block otherwise. ----
+template <int TS, bool INVERSE>
+__global__ __launch_bounds__(64) void k_shuffle_vec_blocks(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint32_t blocksize, uint32_t tiles_per_block) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
+    const uint32_t b = blockIdx.x / tiles_per_block, t = blockIdx.x % tiles_per_block;
+    const size_t base = (size_t)b * blocksize;
+    if (INVERSE) unshuffle_tile<TS>(dst + base, src + base, blocksize / TS, t, slab, threadIdx.x);
+    else shuffle_tile<TS>(dst + base, src + base, blocksize / TS, t, slab, threadIdx.x);
+}
+// returns true when it took the job: typesize 2 / 4 / 8 / 16, blocks of whole 1024-element tiles, nfull whole blocks
+bool hb_launch_shuffle_blocks(bool inverse, uint8_t *dst, const uint8_t *src, uint32_t nfull, uint32_t blocksize, int typesize, hipStream_t s) {
+    if (!(typesize == 2 || typesize == 4 || typesize == 8 || typesize == 16) || nfull == 0) return false;
+    if (blocksize % ((uint32_t)typesize * TILE_ELEMS) != 0) return false;
+    const uint32_t tpb = blocksize / (uint32_t)typesize / TILE_ELEMS;
+    if ((uint64_t)nfull * tpb > 0x7FFFFFFFull) return false;
+    const dim3 g(nfull * tpb);
+    switch (typesize) {
+    case 2: if (inverse) hipLaunchKernelGGL((k_shuffle_vec_blocks<2, true>), g, dim3(64), 0, s, dst, src, blocksize, tpb); else hipLaunchKernelGGL((k_shuffle_vec_blocks<2, false>), g, dim3(64), 0, s, dst, src, blocksize, tpb); break;
+    case 4: if (inverse) hipLaunchKernelGGL((k_shuffle_vec_blocks<4, true>), g, dim3(64), 0, s, dst, src, blocksize, tpb); else hipLaunchKernelGGL((k_shuffle_vec_blocks<4, false>), g, dim3(64), 0, s, dst, src, blocksize, tpb); break;
+    case 8: if (inverse) hipLaunchKernelGGL((k_shuffle_vec_blocks<8, true>), g, dim3(64), 0, s, dst, src, blocksize, tpb); else hipLaunchKernelGGL((k_shuffle_vec_blocks<8, false>), g, dim3(64), 0, s, dst, src, blocksize, tpb); break;
+    default: if (inverse) hipLaunchKernelGGL((k_shuffle_vec_blocks<16, true>), g, dim3(64), 0, s, dst, src, blocksize, tpb); else hipLaunchKernelGGL((k_shuffle_vec_blocks<16, false>), g, dim3(64), 0, s, dst, src, blocksize, tpb); break;
+    }
+    return true;
+}
+
 // ---- batches (hb_*_frames_batch_dev): the same filter on `njobs` independent buffers in one or two launches.  d_jobs: device array;
 // max_n: the largest job (sizes the grid; jobs smaller than that leave their surplus workgroups at once).  Identity cases
 // (typesize <= 1, n < typesize: shuffle.go:17-19) are the caller's: it points the consumer at the source instead. ----

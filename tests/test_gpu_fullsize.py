@@ -122,3 +122,68 @@ def test_config5_float32_shuffle_zstd_1gib(hb, O):
     back = np.empty(GIB, np.uint8)
     assert L.hb_decompress_frame(out.ctypes.data, c, back.ctypes.data, GIB, 0, 0) == GIB
     assert np.array_equal(back, x), "device decode of the ZSTD frame differs"
+
+
+def _multi_job(hb, O, kind, nframes, elems, codec, level, shuffle, ts, opts):
+    """BASELINE.json configs 4 / 5 as the JOB they are: `nframes` independent frames through hb_compress_frames_multi /
+    hb_decompress_frames_multi (frame k on device k mod G, one host thread + one 3-deep queue per device; here G = the devices of
+    the box).  Every frame is checked on its own: header, the oracle's (= the reference decoder's) decode of it, the device's."""
+    import ctypes
+    L = hb.lib()
+    xs = [O.synth(kind, elems, frame=k) for k in range(nframes)]
+    n = xs[0].size
+    caps = [L.hb_frame_bound(n)] * nframes
+    outs = [np.empty(c, np.uint8) for c in caps]
+    vp, sz, i64 = ctypes.c_void_p * nframes, ctypes.c_size_t * nframes, ctypes.c_int64 * nframes
+    rcs = i64()
+    assert L.hb_compress_frames_multi(nframes, vp(*[x.ctypes.data for x in xs]), sz(*([n] * nframes)), vp(*[o.ctypes.data for o in outs]),
+                                      sz(*caps), rcs, codec, level, shuffle, ts, opts) == 0
+    assert all(r > 16 for r in rcs), list(rcs)
+    frames = [outs[k][: rcs[k]] for k in range(nframes)]
+    backs = [np.zeros(n, np.uint8) for _ in range(nframes)]
+    rcd = i64()
+    assert L.hb_decompress_frames_multi(nframes, vp(*[f.ctypes.data for f in frames]), sz(*[f.size for f in frames]),
+                                        vp(*[b.ctypes.data for b in backs]), sz(*([n] * nframes)), rcd, 0) == 0
+    assert all(r == n for r in rcd), list(rcd)
+    for k in range(nframes):
+        assert np.array_equal(backs[k], xs[k]), f"frame {k}: multi round trip differs"
+    return xs, frames
+
+
+def test_config4_eight_frame_job_through_multi(hb, O):
+    # config 4: 8 frames of int32, BitShuffle typesize 4 + LZ4, "blocks sharded across 8 MI355X" -- 256 MiB per frame here (the job's
+    # shape at a quarter of its size: 8 x 1 GiB of pinned-free host buffers x 3 is more than this box's share of host memory)
+    n = 256 << 20
+    xs, frames = _multi_job(hb, O, O.D_I32, 8, n // 4, hb.LZ4, 5, hb.BitShuffle, 4, hb.OPT_INDEX_TRAILER)
+    for k, (x, f) in enumerate(zip(xs, frames)):
+        h = hb.ParseHeader(f[:16].tobytes())
+        assert (h.Version, h.VersionLZ, h.Flags, h.TypeSize, h.NBytesOrig, h.BlockSize) == (2, hb.LZ4, 0x4, 4, n, n) and not h.IsMemcpy()
+        assert 0.55 < h.NBytesComp / n < 0.70
+        assert np.array_equal(O.decompress_frame(f), x), f"frame {k}: the oracle (reference decoder) cannot reproduce the input"
+    assert len({f[16:4096].tobytes() for f in frames}) == 8, "the frames of the job must differ (frame k = data set k)"
+
+
+def test_config5_eight_frame_job_through_multi(hb, O):
+    # config 5: 8 frames of float32, device Shuffle1 overlapped with host ZSTD level 3, through the same entry points (host codec frames
+    # take the one-call path inside them, one frame per device at a time)
+    import ctypes
+    import os
+    zs = None
+    for p in ("/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"):
+        if os.path.exists(p):
+            zs = ctypes.CDLL(p)
+            break
+    if zs is None:
+        pytest.skip("libzstd not in this image")
+    zs.ZSTD_decompress.restype = ctypes.c_size_t
+    zs.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    n = 256 << 20
+    xs, frames = _multi_job(hb, O, O.D_F32, 8, n // 4, hb.ZSTD, 3, hb.Shuffle1, 4, 0)
+    filt = np.empty(n, np.uint8)
+    for k, (x, f) in enumerate(zip(xs, frames)):
+        h = hb.ParseHeader(f[:16].tobytes())
+        assert (h.Version, h.VersionLZ, h.Flags, h.TypeSize, h.NBytesOrig, h.NBytesComp) == (2, hb.ZSTD, 0x1, 4, n, f.size)
+        assert 0.30 < f.size / n < 0.45
+        r = zs.ZSTD_decompress(filt.ctypes.data, n, f.ctypes.data + 16, f.size - 16)
+        assert r == n, f"frame {k}: libzstd cannot decode the payload as one concatenation of frames"
+        assert np.array_equal(O.filter(O.OP_UNSHUFFLE, filt, 4), x), f"frame {k}: libzstd + oracle unshuffle cannot reproduce the input"
