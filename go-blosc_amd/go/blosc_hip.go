@@ -431,3 +431,146 @@ func DecompressCBlosc(frame []byte) ([]byte, error) {
 	}
 	return buf[:n], nil
 }
+
+// ---------------------------------------------------------------------------------------------
+// Batches of SMALL frames: many independent Compress / Decompress calls (blosc.go:257-303) through ONE set of kernel
+// launches (hb_compress_frames_batch / hb_decompress_frames_batch).  The reference's own benchmark frame is 100 000 bytes
+// (blosc_test.go:363-371): one such frame cannot fill a GPU, and below MinOffloadBytes CompressHIP leaves it to the CPU;
+// a batch of them is a different matter (4096 x 100 000 B: ~400 GB/s device-resident, include/hipblosc.h).  Every frame is
+// byte-identical to what CompressHIP writes for the same input; errs[k] carries the reference's sentinel for frame k.
+// Go memory is borrowed for the call only: the pointer arrays live in C memory and hold pinned staging buffers
+// (C pointers), never Go pointers (cgo rule).
+// ---------------------------------------------------------------------------------------------
+func CompressBatchHIP(datas [][]byte, opts Options, withIndex bool) ([][]byte, []error) {
+	n := len(datas)
+	out := make([][]byte, n)
+	errs := make([]error, n)
+	if n == 0 {
+		return out, errs
+	}
+	if !useHIP || !(opts.Codec == LZ4 || opts.Codec == LZ4HC) {
+		for k, d := range datas {
+			out[k], errs[k] = CompressHIP(d, opts, withIndex)
+		}
+		return out, errs
+	}
+	srcs := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	dsts := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	defer C.free(unsafe.Pointer(&srcs[0]))
+	defer C.free(unsafe.Pointer(&dsts[0]))
+	lens := make([]C.size_t, n)
+	caps := make([]C.size_t, n)
+	rcs := make([]C.int64_t, n)
+	// one pinned slab for all inputs and one for all outputs: two allocations per batch, not two per frame
+	var inBytes, outBytes C.size_t
+	for k, d := range datas {
+		lens[k] = C.size_t(len(d))
+		caps[k] = C.hb_frame_bound(lens[k])
+		inBytes += (lens[k] + 63) &^ 63
+		outBytes += (caps[k] + 63) &^ 63
+	}
+	slabIn, slabOut := C.hb_host_alloc(inBytes+64), C.hb_host_alloc(outBytes+64)
+	if slabIn == nil || slabOut == nil {
+		C.hb_host_free(slabIn)
+		C.hb_host_free(slabOut)
+		for k, d := range datas {
+			out[k], errs[k] = CompressHIP(d, opts, withIndex)
+		}
+		return out, errs
+	}
+	defer C.hb_host_free(slabIn)
+	defer C.hb_host_free(slabOut)
+	var io, oo C.size_t
+	for k, d := range datas {
+		srcs[k] = unsafe.Add(slabIn, uintptr(io))
+		dsts[k] = unsafe.Add(slabOut, uintptr(oo))
+		copy(unsafe.Slice((*byte)(srcs[k]), len(d)), d)
+		io += (lens[k] + 63) &^ 63
+		oo += (caps[k] + 63) &^ 63
+	}
+	var o C.uint
+	if withIndex {
+		o |= C.HB_OPT_INDEX_TRAILER
+	}
+	if rc := C.hb_compress_frames_batch(C.int(n), &srcs[0], &lens[0], &dsts[0], &caps[0], &rcs[0],
+		C.int(opts.Codec), C.int(opts.Level), C.int(opts.Shuffle), C.int(opts.TypeSize), o, C.int(Device)); rc != C.HB_OK {
+		for k := range datas {
+			errs[k] = hbError(C.int64_t(rc))
+		}
+		return out, errs
+	}
+	for k := range datas {
+		if rcs[k] < 0 {
+			errs[k] = hbError(rcs[k])
+		} else {
+			out[k] = append([]byte(nil), unsafe.Slice((*byte)(dsts[k]), int(rcs[k]))...)
+		}
+	}
+	return out, errs
+}
+
+// DecompressBatchHIP: the inverse; frames of any writer (this library with or without the restart index, the pure-Go path).
+func DecompressBatchHIP(frames [][]byte) ([][]byte, []error) {
+	n := len(frames)
+	out := make([][]byte, n)
+	errs := make([]error, n)
+	if n == 0 {
+		return out, errs
+	}
+	if !useHIP {
+		for k, f := range frames {
+			out[k], errs[k] = Decompress(f)
+		}
+		return out, errs
+	}
+	srcs := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	dsts := (*[1 << 28]unsafe.Pointer)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	defer C.free(unsafe.Pointer(&srcs[0]))
+	defer C.free(unsafe.Pointer(&dsts[0]))
+	lens := make([]C.size_t, n)
+	caps := make([]C.size_t, n)
+	rcs := make([]C.int64_t, n)
+	var inBytes, outBytes C.size_t
+	for k, f := range frames {
+		lens[k] = C.size_t(len(f))
+		caps[k] = 1
+		if h, err := ParseHeader(f); err == nil {
+			caps[k] = C.size_t(h.NBytesOrig) + 1 // (untrusted: a forged size only costs pinned memory, hb_host_alloc answers nil when there is none)
+		}
+		inBytes += (lens[k] + 63) &^ 63
+		outBytes += (caps[k] + 63) &^ 63
+	}
+	slabIn, slabOut := C.hb_host_alloc(inBytes+64), C.hb_host_alloc(outBytes+64)
+	if slabIn == nil || slabOut == nil {
+		C.hb_host_free(slabIn)
+		C.hb_host_free(slabOut)
+		for k, f := range frames {
+			out[k], errs[k] = DecompressHIP(f, 0)
+		}
+		return out, errs
+	}
+	defer C.hb_host_free(slabIn)
+	defer C.hb_host_free(slabOut)
+	var io, oo C.size_t
+	for k, f := range frames {
+		srcs[k] = unsafe.Add(slabIn, uintptr(io))
+		dsts[k] = unsafe.Add(slabOut, uintptr(oo))
+		copy(unsafe.Slice((*byte)(srcs[k]), len(f)), f)
+		io += (lens[k] + 63) &^ 63
+		oo += (caps[k] + 63) &^ 63
+	}
+	if rc := C.hb_decompress_frames_batch(C.int(n), &srcs[0], &lens[0], &dsts[0], &caps[0], &rcs[0], 0, C.int(Device)); rc != C.HB_OK {
+		for k := range frames {
+			errs[k] = hbError(C.int64_t(rc))
+		}
+		return out, errs
+	}
+	for k := range frames {
+		if rcs[k] < 0 {
+			errs[k] = hbError(rcs[k])
+		} else {
+			out[k] = append([]byte(nil), unsafe.Slice((*byte)(dsts[k]), int(rcs[k]))...)
+		}
+	}
+	return out, errs
+}
