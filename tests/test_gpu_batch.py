@@ -120,3 +120,42 @@ def test_batch_argument_errors(hb, O):
     assert sn == [hb.Compress(xs[0], hb.Snappy, 5, hb.Shuffle1, 4), hb.Compress(xs[2], hb.Snappy, 5, hb.Shuffle1, 4)]
     assert hb.DecompressBatch(sn + [fr[0]]) == [xs[0], xs[2], xs[0]]
     assert hb.CompressBatch([]) == [] and hb.DecompressBatch([]) == []
+
+
+def test_random_blocks_and_mutations_in_one_batch(hb, O):
+    # blocks no encoder wrote (tests/tools/lz4_stream_gen.py: offsets to 65535, every small period, long runs and literal runs, sequences without
+    # literals) as frames with every filter flag, next to mutated copies: the batch decoder must return, frame by frame, what the one-frame
+    # decoder returns -- and that one is held to the oracle (test_gpu_foreign.py, test_gpu_fuzz.py)
+    import os
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import lz4_stream_gen as G
+    rng = np.random.default_rng(77)
+    frames = []
+    for k in range(40):
+        flags, ts = ((0, 1), (1, 4), (4, 4), (1, 8), (1, 2), (4, 8))[k % 6]
+        block, n = G.random_block(rng, int(rng.integers(2000, 300000)), regime_len=(4 << 10) << (k % 5), align=32 if flags == 4 else ts)
+        f = struct.pack("<BBBBIII", 2, hb.LZ4 if k % 3 else hb.LZ4HC, flags, ts, n, n, 16 + len(block)) + block
+        frames.append(f)
+        if k % 4 == 0:                                                            # damaged copies: payload bit flips, wrong sizes, truncation
+            g = bytearray(f); p = int(rng.integers(16, len(f))); g[p] ^= 1 << int(rng.integers(0, 8)); frames.append(bytes(g))
+            g = bytearray(f); g[4:8] = (n + int(rng.integers(1, 5000))).to_bytes(4, "little"); frames.append(bytes(g))
+            frames.append(f[: 16 + (len(f) - 16) // 2][:12] + (16 + (len(f) - 16) // 2).to_bytes(4, "little") + f[16: 16 + (len(f) - 16) // 2])
+    got = hb.DecompressBatch(frames)
+    agree_err = 0
+    for i, f in enumerate(frames):
+        try:
+            want = hb.Decompress(f)
+        except hb.BloscError as e:
+            want = type(e)
+        if isinstance(want, type):
+            assert isinstance(got[i], want), (i, got[i], want)
+            agree_err += 1
+        else:
+            assert got[i] == want, i
+    assert agree_err >= 5
+    # one frame's oracle check per filter kind: the one-frame decoder above is not the only witness
+    for i in (0, 1, 2):
+        f = [x for x in frames if x[2] == (0, 1, 4)[i]][0]
+        assert got[frames.index(f)] == O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes()
