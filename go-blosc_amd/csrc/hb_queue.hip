@@ -201,9 +201,13 @@ int64_t hb_queue_wait(hb_queue *q, int64_t ticket) {
 // the one-call entry points, which also produce the reference's error for them.  No device talks to another one.
 namespace {
 constexpr int MULTI_DEPTH = 3;
+// Small frames of a device's share do not go through the queue one by one (a 1 MiB frame is 200 us of launches and synchronisation
+// for 2 us of kernel): they are collected and sent through the batch entry points (hb_batch.hip: one set of launches for all of them),
+// MULTI_BATCH_BYTES of input at a time.  What counts as small: up to MULTI_SMALL bytes (uncompressed).
+constexpr size_t MULTI_SMALL = (size_t)4 << 20, MULTI_BATCH_BYTES = (size_t)256 << 20;
 
 template <class Submit, class OneCall>
-void run_device(int dev, int nd, int nframes, size_t max_n, unsigned qflags, int64_t *rc, Submit submit, OneCall one_call) {
+void run_device(int dev, int nd, int nframes, size_t max_n, unsigned qflags, int64_t *rc, const std::vector<char> &done, Submit submit, OneCall one_call) {
     hb_queue *q = max_n ? hb_queue_create_ex(dev, MULTI_DEPTH, max_n, qflags) : nullptr;
     std::vector<std::pair<int, int64_t>> inflight;        // {frame, ticket}
     auto retire = [&](size_t keep) {
@@ -213,6 +217,7 @@ void run_device(int dev, int nd, int nframes, size_t max_n, unsigned qflags, int
         }
     };
     for (int k = dev; k < nframes; k += nd) {
+        if (done[(size_t)k]) continue;                     // went through a batch
         int64_t t = q ? submit(q, k) : (int64_t)HB_ERR_BAD_ARG;
         if (t >= 0) { inflight.push_back({k, t}); retire(MULTI_DEPTH - 1); }
         else rc[k] = one_call(k, dev);                     // not a queue frame: one call (also yields the right error code)
@@ -231,11 +236,32 @@ int hb_compress_frames_multi(int nframes, const void *const *src, const size_t *
     std::vector<std::thread> th;
     for (int d = 0; d < nd && d < nframes; d++) {
         th.emplace_back([=]() {
+            // small frames of this device: batches (LZ4 / LZ4HC: the codecs the batch kernels carry)
+            std::vector<char> batched((size_t)nframes, 0);
+            if (codec == HB_LZ4 || codec == HB_LZ4HC) {
+                std::vector<int> ks;
+                size_t bytes = 0;
+                auto flush = [&]() {
+                    if (ks.size() < 2) { for (int k : ks) batched[(size_t)k] = 0; ks.clear(); bytes = 0; return; }   // a lone small frame: the queue
+                    const int m = (int)ks.size();
+                    std::vector<const void *> ps((size_t)m); std::vector<void *> pd((size_t)m); std::vector<size_t> ns((size_t)m), cs((size_t)m); std::vector<int64_t> rs((size_t)m, HB_ERR_HIP);
+                    for (int i = 0; i < m; i++) { ps[(size_t)i] = src[ks[(size_t)i]]; pd[(size_t)i] = dst[ks[(size_t)i]]; ns[(size_t)i] = n[ks[(size_t)i]]; cs[(size_t)i] = cap[ks[(size_t)i]]; }
+                    const int st = hb_compress_frames_batch(m, ps.data(), ns.data(), pd.data(), cs.data(), rs.data(), codec, level, shuffle, typesize, opts, d);
+                    for (int i = 0; i < m; i++) rc[ks[(size_t)i]] = st ? (int64_t)st : rs[(size_t)i];
+                    ks.clear(); bytes = 0;
+                };
+                for (int k = d; k < nframes; k += nd) {
+                    if (!src[k] || !dst[k] || n[k] == 0 || n[k] > MULTI_SMALL) continue;
+                    batched[(size_t)k] = 1; ks.push_back(k); bytes += n[k];
+                    if (bytes >= MULTI_BATCH_BYTES) flush();
+                }
+                flush();
+            }
             size_t max_n = 0;
             if (hb_device_codec(codec))
                 for (int k = d; k < nframes; k += nd)
-                    if (n[k] <= 0xFFFFFFFFull - HB_HEADER_SIZE - n[k] / 255 - 64) max_n = std::max(max_n, n[k]);
-            run_device(d, nd, nframes, max_n, 0u, rc,
+                    if (!batched[(size_t)k] && n[k] <= 0xFFFFFFFFull - HB_HEADER_SIZE - n[k] / 255 - 64) max_n = std::max(max_n, n[k]);
+            run_device(d, nd, nframes, max_n, 0u, rc, batched,
                        [&](hb_queue *q, int k) -> int64_t {
                            if (!hb_device_codec(codec) || !src[k] || !dst[k] || n[k] == 0) return HB_ERR_BAD_ARG;
                            return hb_queue_compress(q, src[k], n[k], dst[k], cap[k], codec, level, shuffle, typesize, opts);
@@ -255,10 +281,33 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
     std::vector<std::thread> th;
     for (int d = 0; d < nd && d < nframes; d++) {
         th.emplace_back([=]() {
+            // small frames of this device: batches (frames the batch entry point cannot carry are answered by the one-frame one inside it)
+            std::vector<char> batched((size_t)nframes, 0);
+            {
+                std::vector<int> ks;
+                size_t bytes = 0;
+                auto flush = [&]() {
+                    if (ks.size() < 2) { for (int k : ks) batched[(size_t)k] = 0; ks.clear(); bytes = 0; return; }
+                    const int m = (int)ks.size();
+                    std::vector<const void *> ps((size_t)m); std::vector<void *> pd((size_t)m); std::vector<size_t> ns((size_t)m), cs((size_t)m); std::vector<int64_t> rs((size_t)m, HB_ERR_HIP);
+                    for (int i = 0; i < m; i++) { ps[(size_t)i] = frame[ks[(size_t)i]]; pd[(size_t)i] = dst[ks[(size_t)i]]; ns[(size_t)i] = n[ks[(size_t)i]]; cs[(size_t)i] = cap[ks[(size_t)i]]; }
+                    const int st = hb_decompress_frames_batch(m, ps.data(), ns.data(), pd.data(), cs.data(), rs.data(), typesize_override, d);
+                    for (int i = 0; i < m; i++) rc[ks[(size_t)i]] = st ? (int64_t)st : rs[(size_t)i];
+                    ks.clear(); bytes = 0;
+                };
+                for (int k = d; k < nframes; k += nd) {
+                    hb_header h;
+                    if (!frame[k] || hb_parse_header(frame[k], n[k], &h) != HB_OK || (size_t)h.nbytes > MULTI_SMALL || (size_t)h.nbytes > cap[k] || (!dst[k] && cap[k])) continue;
+                    batched[(size_t)k] = 1; ks.push_back(k); bytes += h.nbytes;
+                    if (bytes >= MULTI_BATCH_BYTES) flush();
+                }
+                flush();
+            }
             size_t max_n = 0;                              // largest decoded size among this device's well-formed LZ4 frames
             unsigned qflags = 0;                           // any large LZ4 frame without a trailer: it may be somebody else's
             for (int k = d; k < nframes; k += nd) {
                 hb_header h;
+                if (batched[(size_t)k]) continue;
                 // frames whose header asks for more than the caller gave (nbytes above cap[k], cbytes above n[k]) never reach a queue slot:
                 // they must not size the slots either (one forged NBytesOrig made every device allocate 3 x ~3 x 4 GiB); the
                 // one-call path answers them with the reference's error
@@ -270,7 +319,7 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
                 }
             }
             if (max_n > 0xFFFFFFFFull - HB_HEADER_SIZE - max_n / 255 - 64) max_n = 0;
-            run_device(d, nd, nframes, max_n, qflags, rc,
+            run_device(d, nd, nframes, max_n, qflags, rc, batched,
                        [&](hb_queue *q, int k) -> int64_t {
                            if (!frame[k] || (!dst[k] && cap[k])) return HB_ERR_BAD_ARG;
                            return hb_queue_decompress(q, frame[k], n[k], dst[k], cap[k], typesize_override);

@@ -159,3 +159,44 @@ def test_random_blocks_and_mutations_in_one_batch(hb, O):
     for i in (0, 1, 2):
         f = [x for x in frames if x[2] == (0, 1, 4)[i]][0]
         assert got[frames.index(f)] == O.decompress_frame(np.frombuffer(f, np.uint8)).tobytes()
+
+
+def test_frames_multi_batches_its_small_frames(hb, O):
+    # hb_compress_frames_multi / hb_decompress_frames_multi send the small frames of every device's share through the batch kernels and
+    # the large ones through the device's queue: 200 frames of 20 KB - 1.2 MiB around two frames of 6 MiB -- same bytes as one call each
+    import ctypes
+    L = hb.lib()
+    rng = np.random.default_rng(9)
+    xs = [O.synth(O.D_F32, int(rng.integers(5000, 300000)), frame=k) for k in range(200)]
+    xs.insert(17, O.synth(O.D_F32, 6 << 18, frame=300)); xs.insert(120, O.synth(O.D_I32, 6 << 18, frame=301))
+    xs.append(rng.integers(0, 256, 50000, dtype=np.uint8))                                 # -> memcpy frame
+    m = len(xs)
+    caps = [L.hb_frame_bound(x.size) for x in xs]
+    outs = [np.empty(c, np.uint8) for c in caps]
+    vp, sz, i64 = ctypes.c_void_p * m, ctypes.c_size_t * m, ctypes.c_int64 * m
+    rcs = i64()
+    assert L.hb_compress_frames_multi(m, vp(*[x.ctypes.data for x in xs]), sz(*[x.size for x in xs]), vp(*[o.ctypes.data for o in outs]), sz(*caps), rcs,
+                                      hb.LZ4, 5, hb.Shuffle1, 4, hb.OPT_INDEX_TRAILER) == 0
+    frames = []
+    for k in range(m):
+        assert rcs[k] > 16, (k, rcs[k])
+        f = outs[k][: rcs[k]].tobytes()
+        if k % 9 == 0 or xs[k].size > (4 << 20):
+            assert f == hb.Compress(xs[k].tobytes(), hb.LZ4, 5, hb.Shuffle1, 4, opts=hb.OPT_INDEX_TRAILER), k
+            h = hb.GetInfo(f)
+            if not h.IsMemcpy():
+                assert np.array_equal(O.decompress_frame(np.frombuffer(f, np.uint8)), xs[k]), k
+        frames.append(np.frombuffer(f, np.uint8).copy())
+    # a foreign (oracle-written) frame and a damaged one among them on the way back
+    frames[5] = O.compress_frame(xs[5], shuffle=1, typesize=4)
+    bad = frames[6].copy(); bad[0] = 9
+    backs = [np.zeros(max(x.size, 16), np.uint8) for x in xs]
+    rcd = i64()
+    fr2 = list(frames); fr2[6] = bad
+    assert L.hb_decompress_frames_multi(m, vp(*[f.ctypes.data for f in fr2]), sz(*[f.size for f in fr2]), vp(*[b.ctypes.data for b in backs]),
+                                        sz(*[b.size for b in backs]), rcd, 0) == 0
+    for k in range(m):
+        if k == 6:
+            assert rcd[k] == -3, rcd[k]                                                    # ErrInvalidVersion for that frame only
+        else:
+            assert rcd[k] == xs[k].size and np.array_equal(backs[k][: xs[k].size], xs[k]), (k, rcd[k])

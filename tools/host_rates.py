@@ -5,6 +5,7 @@
   python tools/host_rates.py queue        the same frames through hb_queue_* (3 in flight) next to the one-call API
   python tools/host_rates.py small        small frames (1-16 MiB) through hb_queue_* at several depths (launch-latency regime)
   python tools/host_rates.py config5      BASELINE.json config 5: 1 GiB D-f32, device Shuffle1 overlapped with host ZSTD level 3
+  python tools/host_rates.py batch        1024 x 1 MiB and 4096 x 100 000 B frames through hb_*_frames_batch and hb_*_frames_multi (host to host)
   python tools/host_rates.py multi        hb_compress_frames_multi / hb_decompress_frames_multi on 8 x 256 MiB frames (all visible GPUs)
 
 These are never the `value` of bench.py (device-resident by contract); `bench.py --host` embeds the first two.
@@ -120,9 +121,43 @@ def multi(L):
           f"{nf * n / (t1 - t0) / 1e9:.2f} GB/s, decompress {nf * n / (t3 - t2) / 1e9:.2f} GB/s (host->host)", flush=True)
 
 
+def batch(L):
+    """Small frames host to host through the batch entry points (one set of launches per call) and through hb_*_frames_multi, which
+    batches the small frames of every device's share itself; pinned buffers."""
+    for nf, n, label in ((1024, 1 << 20, "1 MiB D-f32"), (4096, 100000, "100 000 B byte(i % 256) (blosc_test.go:363-371)")):
+        if n == 100000:
+            x = np.frombuffer(bytes(i % 256 for i in range(n)), np.uint8)
+            xs = [x] * nf
+        else:
+            big = O.synth(O.D_F32, nf * n // 4)
+            xs = [big[k * n:(k + 1) * n] for k in range(nf)]
+        cap = L.hb_frame_bound(n)
+        slab_in, slab_out = hb.PinnedBuffer(nf * n), hb.PinnedBuffer(nf * ((cap + 63) & ~63))
+        for k, x in enumerate(xs):
+            ctypes.memmove(slab_in.ptr + k * n, x.ctypes.data, n)
+        vp, sz = ctypes.c_void_p * nf, ctypes.c_size_t * nf
+        src = vp(*[slab_in.ptr + k * n for k in range(nf)])
+        dst = vp(*[slab_out.ptr + k * ((cap + 63) & ~63) for k in range(nf)])
+        rcs = (ctypes.c_int64 * nf)()
+        for name, comp, dec in (("frames_batch", lambda: L.hb_compress_frames_batch(nf, src, sz(*[n] * nf), dst, sz(*[cap] * nf), rcs, hb.LZ4, 5, hb.Shuffle1, 4, 0, 0),
+                                 lambda cs: L.hb_decompress_frames_batch(nf, dst, sz(*cs), src, sz(*[n] * nf), rcs, 0, 0)),
+                                ("frames_multi", lambda: L.hb_compress_frames_multi(nf, src, sz(*[n] * nf), dst, sz(*[cap] * nf), rcs, hb.LZ4, 5, hb.Shuffle1, 4, 0),
+                                 lambda cs: L.hb_decompress_frames_multi(nf, dst, sz(*cs), src, sz(*[n] * nf), rcs, 0))):
+            for _ in range(2):
+                t0 = time.perf_counter(); assert comp() == 0; t1 = time.perf_counter()
+            cs = list(rcs)
+            assert min(cs) > 16
+            for _ in range(2):
+                t2 = time.perf_counter(); assert dec(cs) == 0; t3 = time.perf_counter()
+            assert list(rcs) == [n] * nf and all(np.array_equal(arr(slab_in.ptr + k * n, n), xs[k]) for k in (0, nf // 2, nf - 1))
+            print(f"{nf} frames of {label}, default frame shape, {name}: compress {nf * n / (t1 - t0) / 1e9:.2f} GB/s, decompress {nf * n / (t3 - t2) / 1e9:.2f} GB/s "
+                  f"(host->host, ratio {sum(cs) / (nf * n):.3f})", flush=True)
+        slab_in.close(); slab_out.close()
+
+
 if __name__ == "__main__":
     L = hb.lib()
     assert L.hb_init() == 0, "needs a HIP device (no CPU fallback)"
     what = sys.argv[1] if len(sys.argv) > 1 else "queue"
-    {"one-call": one_call, "queue": queue, "config5": config5, "multi": multi,
+    {"one-call": one_call, "queue": queue, "config5": config5, "multi": multi, "batch": batch,
      "small": lambda L: queue(L, ((1, 1, 256), (1, 8, 256), (1, 16, 256), (4, 8, 128), (16, 4, 64)))}[what](L)
