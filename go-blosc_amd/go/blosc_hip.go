@@ -466,7 +466,7 @@ func CompressBatchHIP(datas [][]byte, opts Options, withIndex bool) ([][]byte, [
 	for k, d := range datas {
 		lens[k] = C.size_t(len(d))
 		caps[k] = C.hb_frame_bound(lens[k])
-		inBytes += (lens[k] + 63) &^ 63
+		inBytes += lens[k] // tightly packed: inputs that follow each other exactly go up in ONE copy (hb_compress_frames_batch)
 		outBytes += (caps[k] + 63) &^ 63
 	}
 	slabIn, slabOut := C.hb_host_alloc(inBytes+64), C.hb_host_alloc(outBytes+64)
@@ -485,7 +485,7 @@ func CompressBatchHIP(datas [][]byte, opts Options, withIndex bool) ([][]byte, [
 		srcs[k] = unsafe.Add(slabIn, uintptr(io))
 		dsts[k] = unsafe.Add(slabOut, uintptr(oo))
 		copy(unsafe.Slice((*byte)(srcs[k]), len(d)), d)
-		io += (lens[k] + 63) &^ 63
+		io += lens[k]
 		oo += (caps[k] + 63) &^ 63
 	}
 	var o C.uint
@@ -537,8 +537,8 @@ func DecompressBatchHIP(frames [][]byte) ([][]byte, []error) {
 		if h, err := ParseHeader(f); err == nil {
 			caps[k] = C.size_t(h.NBytesOrig) + 1 // (untrusted: a forged size only costs pinned memory, hb_host_alloc answers nil when there is none)
 		}
-		inBytes += (lens[k] + 63) &^ 63
-		outBytes += (caps[k] + 63) &^ 63
+		inBytes += lens[k] // frames tightly packed: one upload; results spaced by their capacity: one download (hb_decompress_frames_batch)
+		outBytes += caps[k]
 	}
 	slabIn, slabOut := C.hb_host_alloc(inBytes+64), C.hb_host_alloc(outBytes+64)
 	if slabIn == nil || slabOut == nil {
@@ -556,8 +556,8 @@ func DecompressBatchHIP(frames [][]byte) ([][]byte, []error) {
 		srcs[k] = unsafe.Add(slabIn, uintptr(io))
 		dsts[k] = unsafe.Add(slabOut, uintptr(oo))
 		copy(unsafe.Slice((*byte)(srcs[k]), len(f)), f)
-		io += (lens[k] + 63) &^ 63
-		oo += (caps[k] + 63) &^ 63
+		io += lens[k]
+		oo += caps[k]
 	}
 	if rc := C.hb_decompress_frames_batch(C.int(n), &srcs[0], &lens[0], &dsts[0], &caps[0], &rcs[0], 0, C.int(Device)); rc != C.HB_OK {
 		for k := range frames {

@@ -200,3 +200,48 @@ def test_frames_multi_batches_its_small_frames(hb, O):
             assert rcd[k] == -3, rcd[k]                                                    # ErrInvalidVersion for that frame only
         else:
             assert rcd[k] == xs[k].size and np.array_equal(backs[k][: xs[k].size], xs[k]), (k, rcd[k])
+
+
+def test_adjacent_host_buffers_take_the_one_copy_paths(hb, O):
+    # inputs that follow each other exactly in host memory go up in ONE copy, many small frames come down packed in ONE copy (compress),
+    # results that follow each other inside their capacities come down in ONE copy (decompress): same frames, same bytes, and a failed
+    # frame in the batch switches the download back to one copy per frame without touching its neighbours' results
+    import ctypes
+    L = hb.lib()
+    K, n = 64, 50000
+    xs = [O.synth(O.D_F32, n // 4, frame=k) for k in range(K)]
+    slab = np.concatenate(xs)                                              # exactly adjacent inputs
+    cap = L.hb_frame_bound(n)
+    out = np.zeros(K * cap, np.uint8)
+    vp, sz, i64 = ctypes.c_void_p * K, ctypes.c_size_t * K, ctypes.c_int64 * K
+    rcs = i64()
+    assert L.hb_compress_frames_batch(K, vp(*[slab.ctypes.data + k * n for k in range(K)]), sz(*[n] * K), vp(*[out.ctypes.data + k * cap for k in range(K)]),
+                                      sz(*[cap] * K), rcs, hb.LZ4, 5, hb.Shuffle1, 4, 0, 0) == 0
+    frames = []
+    for k in range(K):
+        f = out[k * cap: k * cap + rcs[k]].tobytes()
+        assert f == hb.Compress(xs[k].tobytes(), hb.LZ4, 5, hb.Shuffle1, 4, opts=0), k
+        frames.append(f)
+    fslab = np.frombuffer(b"".join(frames), np.uint8).copy()               # exactly adjacent frames
+    offs = np.cumsum([0] + [len(f) for f in frames])
+    room = n + 24                                                           # results 24 bytes apart inside their capacities
+    back = np.full(K * room, 0xAB, np.uint8)
+    rcd = i64()
+    assert L.hb_decompress_frames_batch(K, vp(*[fslab.ctypes.data + int(offs[k]) for k in range(K)]), sz(*[len(f) for f in frames]),
+                                        vp(*[back.ctypes.data + k * room for k in range(K)]), sz(*[room] * K), rcd, 0, 0) == 0
+    for k in range(K):
+        assert rcd[k] == n and back[k * room: k * room + n].tobytes() == xs[k].tobytes(), k
+    # one damaged frame among them
+    bad = fslab.copy(); bad[int(offs[7]) + 30: int(offs[7]) + 60] ^= 0xFF
+    back[:] = 0xCD
+    assert L.hb_decompress_frames_batch(K, vp(*[bad.ctypes.data + int(offs[k]) for k in range(K)]), sz(*[len(f) for f in frames]),
+                                        vp(*[back.ctypes.data + k * room for k in range(K)]), sz(*[room] * K), rcd, 0, 0) == 0
+    try:
+        want7 = hb.Decompress(bad[int(offs[7]): int(offs[8])].tobytes())
+    except hb.BloscError as e:
+        want7 = e.code
+    for k in range(K):
+        if k == 7:
+            assert (rcd[k] == want7) if isinstance(want7, int) else (rcd[k] == n and back[k * room: k * room + n].tobytes() == want7)
+        else:
+            assert rcd[k] == n and back[k * room: k * room + n].tobytes() == xs[k].tobytes(), k
