@@ -249,7 +249,7 @@ size_t hb_lz4_decompress_workspace_foreign(size_t n_out) { return ((hb_lz4_dec_w
 int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap, void *d_index, size_t index_cap,
                         void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if (!d_src || !d_dst || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if (!d_src || !d_dst || !d_work || ((uintptr_t)d_work & 255u) || !d_result) return HB_ERR_BAD_ARG;
     if (n > 0xFFFFFFFFull - n / 255 - 64) return HB_ERR_DATA_TOO_LARGE;
     if (cap < hb_lz4_bound(n)) return HB_ERR_SHORT_BUFFER;
     if (work_bytes < hb_lz4_enc_workspace(n)) return HB_ERR_SHORT_BUFFER;
@@ -264,7 +264,7 @@ int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap, vo
 int hb_lz4_decompress_dev(const void *d_src, size_t n, void *d_dst, size_t cap, const void *d_index, size_t index_bytes,
                           void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if ((!d_src && n) || (!d_dst && cap) || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if ((!d_src && n) || (!d_dst && cap) || !d_work || ((uintptr_t)d_work & 255u) || !d_result) return HB_ERR_BAD_ARG;
     if (work_bytes < hb_lz4_dec_workspace(cap)) return HB_ERR_SHORT_BUFFER;
     hb_dec_args a{};
     a.src = (const uint8_t *)d_src; a.n = n; a.dst = (uint8_t *)d_dst; a.cap = cap;
@@ -385,7 +385,7 @@ int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap
                           int typesize, unsigned opts, void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
     if (n == 0) return HB_ERR_INVALID_DATA;                           // blosc.go:269-271
-    if (!d_src || !d_frame || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if (!d_src || !d_frame || !d_work || ((uintptr_t)d_work & 255u) || !d_result) return HB_ERR_BAD_ARG;
     if (typesize <= 0) typesize = 1;                                  // blosc.go:274-276
     if (level < 1) level = 1;                                         // blosc.go:277-279
     if (level > 9) level = 9;                                         // :280-282
@@ -427,7 +427,7 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
                             void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
     if (n < HB_HEADER_SIZE) return HB_ERR_INVALID_HEADER;             // blosc.go:297-299
-    if (!d_frame || !d_work || !d_result || (!d_dst && cap)) return HB_ERR_BAD_ARG;
+    if (!d_frame || !d_work || ((uintptr_t)d_work & 255u) || !d_result || (!d_dst && cap)) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     // The launch shape of the un-filter depends on header fields: read the 16 header bytes back.
     uint8_t hb[HB_HEADER_SIZE];
@@ -443,7 +443,7 @@ int hb_decompress_frame_dev(const void *d_frame, size_t n, void *d_dst, size_t c
 int hb_decompress_frame_dev_hdr(const hb_header *hdr, const void *d_frame, size_t n, void *d_dst, size_t cap, int typesize_override,
                                 void *d_work, size_t work_bytes, hb_result *d_result, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if (!hdr || !d_frame || !d_work || !d_result || (!d_dst && cap)) return HB_ERR_BAD_ARG;
+    if (!hdr || !d_frame || !d_work || ((uintptr_t)d_work & 255u) || !d_result || (!d_dst && cap)) return HB_ERR_BAD_ARG;
     const hb_header &h = *hdr;
     hipStream_t s = (hipStream_t)stream;
     int rc;

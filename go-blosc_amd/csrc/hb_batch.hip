@@ -124,7 +124,7 @@ int hb_compress_frames_batch_dev(int nframes, const void *const *d_src, const si
                                  int codec, int level, int shuffle, int typesize, unsigned opts,
                                  void *d_work, size_t work_bytes, hb_result *d_results, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if (nframes < 0 || (nframes && (!d_src || !n || !d_frame || !cap || !d_work || !d_results))) return HB_ERR_BAD_ARG;
+    if (nframes < 0 || (nframes && (!d_src || !n || !d_frame || !cap || !d_work || ((uintptr_t)d_work & 255u) || !d_results))) return HB_ERR_BAD_ARG;
     if (nframes == 0) return HB_OK;
     if (typesize <= 0) typesize = 1;                                  // blosc.go:274-276
     if (level < 1) level = 1;                                         // :277-282
@@ -186,7 +186,7 @@ int hb_decompress_frames_batch_dev(int nframes, const hb_header *hdrs, const voi
                                    void *const *d_dst, const size_t *cap, int typesize_override,
                                    void *d_work, size_t work_bytes, hb_result *d_results, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if (nframes < 0 || (nframes && (!hdrs || !d_frame || !n || !d_dst || !cap || !d_work || !d_results))) return HB_ERR_BAD_ARG;
+    if (nframes < 0 || (nframes && (!hdrs || !d_frame || !n || !d_dst || !cap || !d_work || ((uintptr_t)d_work & 255u) || !d_results))) return HB_ERR_BAD_ARG;
     if (nframes == 0) return HB_OK;
     if (work_bytes < hb_decompress_frames_batch_workspace(nframes, hdrs)) return HB_ERR_SHORT_BUFFER;
     hipStream_t s = (hipStream_t)stream;

@@ -493,7 +493,7 @@ size_t hb_cblosc_decompress_workspace(size_t nbytes, size_t blocksize, size_t ty
 int hb_cblosc_decompress_dev(const hb_cblosc_header *hdr, const void *d_frame, size_t n, void *d_dst, size_t cap, void *d_work, size_t work_bytes,
                              hb_result *d_result, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if (!hdr || !d_frame || (!d_dst && cap) || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if (!hdr || !d_frame || (!d_dst && cap) || !d_work || ((uintptr_t)d_work & 255u) || !d_result) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t nbytes = hdr->nbytes, blocksize = hdr->blocksize, ts = hdr->typesize, flags = hdr->flags;
     // the record may come from a caller that ignored hb_cblosc_parse_header's return value, or built it itself: repeat its checks
@@ -583,7 +583,7 @@ size_t hb_cblosc_compress_workspace(size_t n, int shuffle, int typesize) { retur
 int hb_cblosc_compress_dev(const void *d_src, size_t n, void *d_frame, size_t cap, int shuffle, int typesize, void *d_work, size_t work_bytes,
                            hb_result *d_result, void *stream) {
     if (hb_init() != HB_OK) return HB_ERR_NO_DEVICE;
-    if ((!d_src && n) || !d_frame || !d_work || !d_result) return HB_ERR_BAD_ARG;
+    if ((!d_src && n) || !d_frame || !d_work || ((uintptr_t)d_work & 255u) || !d_result) return HB_ERR_BAD_ARG;
     if (typesize < 1 || typesize > 255 || shuffle < 0 || shuffle > 2) return HB_ERR_BAD_ARG;
     if (n > 0x7FFFFFFFull - 64u * 1024u * 1024u) return HB_ERR_DATA_TOO_LARGE;           // (c-blosc: BLOSC_MAX_BUFFERSIZE = INT_MAX - 16)
     if (cap < hb_cblosc_bound(n, typesize)) return HB_ERR_SHORT_BUFFER;

@@ -72,7 +72,15 @@ __device__ __forceinline__ void lds_match_lane(uint8_t *out, uint32_t md, uint32
         if (len & 1u) out[md + k] = (uint8_t)pat;
         return;
     }
-    for (uint32_t k = 0; k < len; k++) out[md + k] = out[md - off + k];   // offsets 2..7: byte by byte
+    // offsets 2..7: the first eo bytes one by one, eo = the smallest multiple of the period that is >= 8 (8, 9, 8, 10, 12, 14) -- from there
+    // on out[md + k] = out[md + k - eo] reads 8 bytes that are all written already (64 bytes: 8-14 + 7 steps instead of 64)
+    const uint32_t eo = (0xECA898u >> (4u * (off - 2u))) & 15u;
+    uint32_t k = 0;
+    const uint32_t head = len < eo ? len : eo;
+    for (; k < head; k++) out[md + k] = out[md - off + k];
+    for (; k + 8u <= len; k += 8u) ((hb_u64u *)(out + md + k))->v = ((const hb_u64u *)(out + md + k - eo))->v;
+    if (k + 4u <= len) { ((hb_u32u *)(out + md + k))->v = ((const hb_u32u *)(out + md + k - eo))->v; k += 4u; }
+    for (; k < len; k++) out[md + k] = out[md + k - eo];
 }
 __device__ __forceinline__ uint32_t dec_incl_scan(uint32_t v, int lane) { (void)lane; return wave_incl_scan_dpp(v); }
 

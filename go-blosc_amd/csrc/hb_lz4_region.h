@@ -152,16 +152,17 @@ static inline void rg_regions(size_t n, uint64_t *rs_out, uint32_t *nreg_out) {
 // the rest one at a time with all arguments wave-uniform:
 //   single(tp, ls, lit, mlen, off, tok)  mlen == 0: the block's final, literal-only sequence
 // Returns false when a callback stopped the walk or the stream turned out malformed after all.
-template <class Batch, class Single>
+// PWIN: bytes of the staged stream window (s_win holds PWIN + 128); it moves once less than a quarter of it is left.
+template <uint32_t PWIN = RG_PWIN, class Batch, class Single>
 __device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const uint64_t n_src, const uint32_t start, const uint32_t exitp,
-                                        uint8_t *s_win /* RG_PWIN + 128 */, uint2 *s_tq /* DTQ */, const int lane, Batch &&batch, Single &&single) {
+                                        uint8_t *s_win /* PWIN + 128 */, uint2 *s_tq /* DTQ */, const int lane, Batch &&batch, Single &&single) {
     uint64_t si = start, wpos = 0;
     uint32_t wlen = 0, wsh = 0, nq = 0;
     auto refill = [&](uint64_t at) __attribute__((always_inline)) {
         const uint8_t *g = src + at;
         wsh = (uint32_t)((uintptr_t)g & 15u);
         const uint64_t left = n_src - at;
-        wlen = (uint32_t)(left < (uint64_t)(RG_PWIN - 16u) ? left : (uint64_t)(RG_PWIN - 16u));
+        wlen = (uint32_t)(left < (uint64_t)(PWIN - 16u) ? left : (uint64_t)(PWIN - 16u));
         const u32x4 *ga = (const u32x4 *)(g - wsh);
         const uint32_t nv = (wsh + wlen + 15u) >> 4;
         wave_sync();
@@ -188,7 +189,7 @@ __device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const u
     };
     wave_sync();
     while (si < exitp) {
-        if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) { if (!drain(true)) return false; refill(si); } }
+        if (si < wpos || si - wpos + PWIN / 4u > wlen) { if (si != wpos || wlen == 0) { if (!drain(true)) return false; refill(si); } }
         uint32_t rel = (uint32_t)(si - wpos);
         const uint64_t tolim = (uint64_t)exitp - wpos;
         const uint32_t lim = (uint32_t)(tolim < (uint64_t)wlen ? tolim : (uint64_t)wlen);
@@ -199,7 +200,7 @@ __device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const u
         if (moved && !stop) continue;
         if (!drain(true)) return false;
         if (si >= exitp) break;
-        if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src && wpos + wlen < exitp) continue;
+        if (moved && si - wpos + PWIN / 4u > wlen && wpos + wlen < n_src && wpos + wlen < exitp) continue;
         // ---- one token the slow way: runs of any length ----
         if (si < wpos || si >= wpos + wlen) refill(si);
         rel = (uint32_t)(si - wpos);

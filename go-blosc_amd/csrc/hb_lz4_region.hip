@@ -564,8 +564,8 @@ __global__ __launch_bounds__(1024) void k_rg_scan(RgPlan *plan, RgRegion *reg, u
 // output position in hand; a unit boundary that falls on a token start or inside a literal run becomes an entry; one that falls
 // inside a match (or at its start) means the block was not written chunk-locally: no index, the single wavefront decodes. ----
 __device__ __forceinline__ void rg_emit(uint8_t *ents, uint64_t U, uint32_t s_off, uint32_t lit_rem, uint32_t tok_off) {
-    uint32_t *e = (uint32_t *)(ents + (U / HB_CHUNK) * HB_IDX_ENTRY);
-    e[0] = s_off; e[1] = (uint32_t)U; e[2] = lit_rem; e[3] = tok_off;
+    u32x4 v; v.x = s_off; v.y = (uint32_t)U; v.z = lit_rem; v.w = tok_off;
+    *(u32x4 *)(ents + (U / HB_CHUNK) * HB_IDX_ENTRY) = v;                  // (entries are HB_IDX_ENTRY = 16 bytes, the table is 16-byte aligned)
 }
 // Round 3: the walk below costs a wavefront about a microsecond per 64 stream bytes (~0.5 ms for a 34 KiB region, 1.1 ms per GiB for
 // the launch) only to find the unit boundaries inside the region.  The first parse left a record of where it was at the start of each
@@ -587,7 +587,9 @@ __device__ __forceinline__ uint32_t rg_rd4(const uint8_t *__restrict__ src, cons
 }
 // a length extension (bytes 255 ... 255 r) at stream position q: adds it to len, moves q behind it; false: runs off the stream / absurd
 __device__ __forceinline__ bool rg_ext(const uint8_t *__restrict__ src, const uint64_t n_src, uint64_t &q, uint64_t &len) {
-    for (int k = 0; k < 4096; k++) {
+    // (64 steps = a run of 64 KiB: every step is a memory round trip of its own, and a lane that crawls through the 1 MiB extension in front
+    // of an incompressible byte plane keeps its whole launch waiting -- 4096 steps were 0.5 - 1.2 ms per GiB; longer runs go to the wave walk)
+    for (int k = 0; k < 64; k++) {
         if (q >= n_src) return false;
         const uint32_t w = rg_rd4(src, n_src, q);
         if (w == 0xFFFFFFFFu && q + 4u <= n_src) { len += 1020u; q += 4u; continue; }
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
     const int lane = threadIdx.x;
     const uint32_t r = blockIdx.x;
     if (lane == 0) done[r] = 0u;
-    if (!plan->ok || plan->fail || r >= plan->nreg) return;
+    if (!plan->ok || __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || r >= plan->nreg) return;
     const uint64_t N = plan->total;
     uint8_t *ents = index + HB_IDX_HDR_BYTES;
     const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit), outlen = RFL(reg[r].outlen), pad0 = RFL(reg[r].pad0);
@@ -633,13 +635,21 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
     if (lane == 0) { uint2 e; e.x = exitp; e.y = outlen; s_tr[nu] = e; }
     wave_sync();
     const uint32_t headend = s_tr[0].x;
-    bool bad = false;
+    bool bad = false, inmatch = false;
+    // a literal run with many unit boundaries in it (an incompressible byte plane is ONE run of 256 MiB: 65536 entries) is left to the
+    // whole wave, below: written by the one lane that came across it, those entries were half of this launch
+    bool hasbig = false;
+    uint64_t bigU = 0, bigG0 = 0, bigEnd = 0;
+    uint32_t bigLs = 0, bigTp = 0;
     for (uint32_t k = (uint32_t)lane; k < nu; k += 64u) {
         const uint32_t send = s_tr[k + 1].x;                            // my segment: the tokens that START in [s_tr[k].x, send)
         uint64_t q = s_tr[k].x;                                         // stream position
         uint64_t d0 = s_tr[k].y;                                        // output position (from `entry`) of the token at q
         for (uint32_t steps = 0; q < send; steps++) {
             if (steps > 1024u) { bad = true; break; }                   // (a bucket holds <= 512 stream bytes of token starts: cannot happen on the chain)
+            // somebody found a unit boundary inside a match: there will be no index, stop walking (another writer's frame says so within
+            // microseconds, and every lane of the launch would otherwise finish its bucket first)
+            if ((steps & 15u) == 15u && __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = true; break; }
             const uint32_t tp = (uint32_t)q;
             const uint32_t w = rg_rd4(src, n_src, q);
             const uint32_t tok = w & 255u;
@@ -669,16 +679,33 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
             const uint64_t g0 = opos + d0;                              // absolute output position of the sequence
             uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
             if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
-            for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
-            if (U < g0 + ll + ml && U < N) { bad = true; break; }       // a unit boundary inside a match: the block was not written chunk-locally
+            if (!hasbig && U + 8u * HB_CHUNK < g0 + ll) {
+                hasbig = true; bigU = U; bigG0 = g0; bigEnd = g0 + ll; bigLs = (uint32_t)ls; bigTp = tp;
+                U += (g0 + ll - 1u - U) / HB_CHUNK * HB_CHUNK + HB_CHUNK;                // the first boundary at or behind the end of the run
+            } else
+                for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
+            if (U < g0 + ll + ml && U < N) { bad = true; inmatch = true; break; }   // a unit boundary inside a match: the block was not written chunk-locally
             d0 += ll + ml;
         }
         if (!bad && (q != send || (uint32_t)d0 != s_tr[k + 1].y)) bad = true;           // my walk must land on the next record exactly
         if (bad) break;
     }
+    // A boundary inside a match, seen from a record of the settled chain (every usable record is a token of it, with its final output
+    // position): the frame has no index, whatever the other regions find -- a frame of another writer says so in its first regions,
+    // and the rest of this launch and the wave walk behind it have nothing left to do (1 GiB as the reference writes it: 1.4 ms).
+    if (hb_ballot(inmatch)) { if (lane == 0) { done[r] = 6u; atomicExch(&plan->fail, 1u); } return; }
     // anything odd: the wave walk does the whole region again, with the machinery the other decoders share (it also decides what a
     // boundary inside a match means for the frame)
     if (hb_ballot(bad)) { if (lane == 0) done[r] = 6u; return; }
+    for (unsigned long long bm = hb_ballot(hasbig); bm; bm &= bm - 1ull) {
+        const int l = __builtin_ctzll(bm);
+        const uint64_t U0 = (uint64_t)__builtin_amdgcn_readlane((uint32_t)bigU, l) | ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bigU >> 32), l) << 32);
+        const uint64_t G0 = (uint64_t)__builtin_amdgcn_readlane((uint32_t)bigG0, l) | ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bigG0 >> 32), l) << 32);
+        uint64_t E = (uint64_t)__builtin_amdgcn_readlane((uint32_t)bigEnd, l) | ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bigEnd >> 32), l) << 32);
+        const uint32_t Ls = __builtin_amdgcn_readlane(bigLs, l), Tp = __builtin_amdgcn_readlane(bigTp, l);
+        const uint64_t lim = E < N ? E : N;
+        for (uint64_t U = U0 + (uint64_t)lane * HB_CHUNK; U < lim; U += 64ull * HB_CHUNK) rg_emit(ents, U, (uint32_t)(Ls + (U - G0)), (uint32_t)(E - U), Tp);
+    }
     if (lane == 0) done[r] = headend;                                   // the head [entry, first usable record) is still to do
 }
 
@@ -692,6 +719,7 @@ __global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src
     const uint64_t N = plan->total;
     uint8_t *ents = index + HB_IDX_HDR_BYTES;
     for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+        if (__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // somebody found a boundary inside a match
         const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit);
         if (RFL(reg[r].outlen) == 0u || start >= exitp) continue;
         // k_rg_index_fast: 0 = nothing done, 0xFFFFFFFF = all of this region's entries written, else only the head [entry, that position) is left

@@ -26,7 +26,29 @@
 // Whatever is wrong with the stream (offset 0, offset before the start of the block) only raises SyPlan.fail: the single wavefront
 // then decodes and reports what lz4.UncompressBlock reports.  A block that passes is decoded to exactly the bytes the serial
 // decoder produces -- every output byte is written from the same source by the same rule, only in a different order.
+// Pass A is bound by one wavefront's latency (round 3, phase clocks: a third of a unit's time is the token walk, a fifth the dependency rounds in
+// LDS, an eighth the fetches from HBM; VALU busy 17 %), so its rate is the number of resident wavefronts: a 2 KiB image (+ 4 KiB of references)
+// and a 2 KiB stream window are 9.3 KiB per wavefront -- 17 per CU instead of 9 -- and 1 GiB of shuffled float32 as the reference writes it
+// takes 3.2 ms instead of 4.7 (3 KiB / 1 KiB history: 3.9; 2 KiB / 1 KiB: 3.25; long sequences suffer below 1.5 KiB of room: a ramp 1.9 -> 2.4).
+#ifndef SY_IMG
+#define SY_IMG   2048u
+#define SY_HIST  512u
+#endif
+#ifndef SY_PWIN
+#define SY_PWIN  2048u
+#endif
+#ifndef SY_WAVES
+#define SY_WAVES 4
+#endif
 #include "hb_sym_decode.h"
+#ifdef SY_DEBUG_TIMES
+__device__ unsigned long long sy_dbg[32];
+extern "C" void hb_debug_sy_times(unsigned long long *out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sy_dbg), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sy_dbg), z, sizeof z); }
+}
+#endif
 
 #define SY_W        65536u        // entries of a tail map / bytes of a tail image (index = distance 1..65535; entry 0 unused)
 #define SY_GROUPS   256u          // groups of units in pass B (128: k_sy_compose 1.9 ms, 256: 1.05, 512: 1.0 but the scan over the groups 0.4)
@@ -155,9 +177,9 @@ __global__ __launch_bounds__(1024) void k_sy_compact(SyPlan *sy, const SyUnit *_
 // and is resumed by the next launch, after k_sy_big has done all posted copies with the whole chip.  The LAST launch copies inline.
 // Unit state between launches (SyUnit): rtp = stream position of the token to resume at (0: not started), rout = output position
 // there, state bit 0 = unit done, bit 1 = that token's literals are copied, bit 2 = its match too.
-__global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ src, uint64_t n_src, SyUnit *un, const uint32_t *__restrict__ list,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SY_WAVES))) void k_sy_decode(const uint8_t *__restrict__ src, uint64_t n_src, SyUnit *un, const uint32_t *__restrict__ list,
                                                    SyPlan *sy, SyBig *big, uint8_t *D, uint16_t *S, int last) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[SY_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     __shared__ __attribute__((aligned(16))) uint8_t s_d[SY_IMG + 64];
     __shared__ __attribute__((aligned(16))) uint16_t s_s[SY_IMG + 64];
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(64) void k_sy_decode(const uint8_t *__restrict__ sr
         const uint32_t start = rtp ? rtp : entry;
         uint32_t out = rtp ? RFL(R->rout) : O;         // next output byte
         bool parked;
-        const bool ok = sy_decode_unit<true>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen));
+        const bool ok = sy_decode_unit<true, SY_PWIN>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen));
         if (!parked) {
             if ((!ok || out != O + RFL(R->outlen)) && lane == 0) atomicExch(&sy->fail, 1u);
             if (lane == 0) R->state = 1u;

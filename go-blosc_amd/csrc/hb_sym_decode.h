@@ -4,8 +4,10 @@
 #pragma once
 #include "hb_lz4_region.h"
 
+#ifndef SY_IMG
 #define SY_IMG      4096u         // bytes of output a wave holds in LDS: the last SY_HIST bytes it wrote to HBM + what it is building
 #define SY_HIST     2048u
+#endif
 #define SY_NCAP     64u           // image-to-image copies up to this long are done by their own lane
 #define SY_BIG      (256u << 10)  // literal runs / matches from this size on are copied by the whole chip (k_sy_big)
 
@@ -13,6 +15,18 @@ struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact; uint32_t pad
 // what one wavefront of pass A decodes: a region of the token discovery, or one of SY_SUB parts of a region whose output is large
 struct SyUnit { uint32_t entry, exit, opos, outlen, rtp, rout, state, pad; };   // state: bit 0 done, bit 1 / 2: literals / match of token rtp copied
 struct SyBig { uint32_t kind, dst, src, len, O, pad[3]; };          // kind 0: literals from stream position src; 1: match, src = offset
+
+#ifdef SY_DEBUG_TIMES
+// phase clocks of pass A (build variant only: scratch/mkvariant.sh sytimes hb_lz4_sym.hip -DSY_DEBUG_TIMES; read by hb_debug_sy_times)
+extern __device__ unsigned long long sy_dbg[32];
+#define SYT_NOW() __builtin_readcyclecounter()
+#define SYT_ADD(slot, t0) do { dbg_t[slot] += SYT_NOW() - (t0); } while (0)
+#define SYT_CNT(slot) do { dbg_t[slot] += 1ull; } while (0)
+#else
+#define SYT_NOW() 0ull
+#define SYT_ADD(slot, t0) do { (void)(t0); } while (0)
+#define SYT_CNT(slot) do { } while (0)
+#endif
 
 // every store of this wave so far has reached the cache all lanes of the CU read through, and later loads are not started early
 __device__ __forceinline__ void sy_sync() {
@@ -132,8 +146,18 @@ __device__ __forceinline__ void sy_near_lane(uint8_t *s_d, uint16_t *s_s, const 
     uint16_t *d = s_s + md;
     const uint16_t *s = d - off;
     uint32_t k = 0;
-    if (off >= 4u) for (; k + 4u <= len; k += 4u) ((hb_u64u *)(d + k))->v = ((const hb_u64u *)(s + k))->v;
-    for (; k < len; k++) d[k] = s[k];
+    if (off >= 4u) {
+        for (; k + 4u <= len; k += 4u) ((hb_u64u *)(d + k))->v = ((const hb_u64u *)(s + k))->v;
+        for (; k < len; k++) d[k] = s[k];
+        return;
+    }
+    // periods 1..3: the first eo entries one by one (eo = 4, 4, 6: the smallest multiple of the period that is >= 4), then four at a time
+    // from eo entries back -- a run of 64 zero bytes that are references is 4 + 15 steps, not 64
+    const uint32_t eo = off == 3u ? 6u : 4u;
+    const uint32_t head = len < eo ? len : eo;
+    for (; k < head; k++) d[k] = s[k];
+    for (; k + 4u <= len; k += 4u) ((hb_u64u *)(d + k))->v = ((const hb_u64u *)(d + k - eo))->v;
+    for (; k < len; k++) d[k] = d[k - eo];
 }
 // ... and the whole wave
 template <bool SYM>
@@ -232,13 +256,17 @@ __device__ __forceinline__ void sy_match_wave(uint8_t *D, uint16_t *S, const uin
 // R / sy / big: where a unit of the symbolic decoder parks in front of a big copy (NULL: never parks).  Returns false when the
 // stream is not what the chain promised (offset 0, offset in front of `base`, a final sequence that announces a match, output past
 // `limit`: nothing is written there).
-template <bool SYM>
+template <bool SYM, uint32_t PWIN = RG_PWIN>
 __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, const uint64_t n_src, const uint32_t start, const uint32_t exitp, const uint32_t base,
                                                const uint32_t O, uint32_t &out, uint8_t *D, uint16_t *S, uint8_t *s_win, uint2 *s_tq, uint8_t *s_d, uint16_t *s_s,
                                                const int lane, const int last, const uint32_t rtp, const uint32_t st, SyUnit *R, SyPlan *sy, SyBig *big, bool &parked,
                                                const uint32_t limit) {
         uint8_t *Sb = (uint8_t *)S;
         parked = false;
+#ifdef SY_DEBUG_TIMES
+        unsigned long long dbg_t[16] = {0};
+        const unsigned long long dbg_t0 = SYT_NOW();
+#endif
         // the image: s_d[i] / s_s[i] = output byte ib + i for i < out - ib; bytes below fl are in HBM already (history kept for near copies)
         uint32_t ib = out, fl = out;
         bool bad = false, unsynced = false;
@@ -246,6 +274,7 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
         auto flush = [&]() __attribute__((always_inline)) {
             const uint32_t n = out - fl;
             if (n == 0u) return;
+            const unsigned long long tq0 = SYT_NOW();
             wave_sync();
             const uint32_t o = fl - ib;
             const uint8_t *s_sb = (const uint8_t *)s_s;
@@ -263,10 +292,13 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             }
             fl = out;
             unsynced = true;                                             // far loads must wait for these stores (sy_sync), not the flush itself
+            SYT_ADD(5, tq0);
         };
         // make room: flush, keep the last SY_HIST bytes as history at the bottom of the image
         auto slide = [&]() __attribute__((always_inline)) {
+            SYT_CNT(11);
             flush();
+            const unsigned long long tq1 = SYT_NOW();
             const uint32_t have = out - ib, keep = have < SY_HIST ? have : SY_HIST, delta = have - keep;
             if (delta) {
                 uint8_t *s_sb = (uint8_t *)s_s;
@@ -282,9 +314,12 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
                 wave_sync();
             }
             ib = out - keep;
+            SYT_ADD(6, tq1);
         };
         auto batch = [&](uint32_t cnt, uint32_t tp, uint32_t ls, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t lp) __attribute__((always_inline)) -> bool {
             (void)tp; (void)ls;
+            SYT_CNT(8);
+            const unsigned long long tb0 = SYT_NOW();
             const bool tok = (uint32_t)lane < cnt;
             const uint32_t olen = tok ? lit + mlen : 0u;
             const uint32_t incl = wave_incl_scan_dpp(olen);
@@ -304,6 +339,8 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
                     // the next sequence does not fit into what is left of the image
                     const uint32_t ol = __builtin_amdgcn_readlane(olen, (int)lo);
                     if (ol > SY_IMG - SY_HIST) {                          // nor behind the history alone: straight in HBM, the whole wave
+                        const unsigned long long th0 = SYT_NOW();
+                        SYT_CNT(12);
                         flush();
                         sy_sync(); unsynced = false;
                         const uint32_t dl = __builtin_amdgcn_readlane(d0, (int)lo), ll = __builtin_amdgcn_readlane(lit, (int)lo);
@@ -312,9 +349,12 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
                         sy_sync();
                         out = dl + ol; ib = out; fl = out;
                         lo++;
+                        SYT_ADD(7, th0);
                     } else slide();
                     continue;
                 }
+                SYT_CNT(9);
+                const unsigned long long tl0 = SYT_NOW();
                 const bool act = tok && (uint32_t)lane >= lo && (uint32_t)lane < hi;
                 const uint32_t t0 = d0 - ib, tm = md - ib;
                 // literals: from the staged stream window
@@ -325,19 +365,28 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
                     sy_lits_img_wave<SYM>(s_d, s_s, __builtin_amdgcn_readlane(t0, l), s_win + __builtin_amdgcn_readlane(lp, l), __builtin_amdgcn_readlane(lit, l), lane);
                     lm &= lm - 1;
                 }
+                SYT_ADD(2, tl0);
                 // the part of every match whose source lies in front of the image: from HBM, all lanes at once (nothing in the batch can
                 // change those bytes)
                 const uint32_t farlen = (act && s0 < ib) ? (ib - s0 < mlen ? ib - s0 : mlen) : 0u;
                 if (hb_ballot(farlen != 0u)) {
-                    if (unsynced) { sy_sync(); unsynced = false; }
+                    SYT_CNT(10);
+                    const unsigned long long ts0 = SYT_NOW();
+                    if (unsynced) { sy_sync(); unsynced = false; SYT_CNT(13); }
+                    SYT_ADD(14, ts0);
+                    const unsigned long long tf0 = SYT_NOW();
                     sy_fetch_lane<SYM>(D, S, s_d, s_s, tm, s0, farlen <= thr ? farlen : 0u, O);
                     lm = hb_ballot(farlen > thr);
                     while (lm) {
                         const int l = __builtin_ctzll(lm);
                         sy_far_wave<SYM>(D, S, s_d, s_s, __builtin_amdgcn_readlane(tm, l), __builtin_amdgcn_readlane(s0, l), __builtin_amdgcn_readlane(farlen, l), O, lane);
                         lm &= lm - 1;
+                        SYT_CNT(15);
                     }
+                    wave_sync();
+                    SYT_ADD(3, tf0);
                 }
+                const unsigned long long tn0 = SYT_NOW();
                 // the rest of every match copies what the image holds: dependency rounds in LDS (the rule of dec_drain, hb_dec_common.h: a
                 // match is ready when its source ends before the first pending match, or starts at / after the end of the nearest
                 // pending match in front of it)
@@ -362,7 +411,9 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
                 }
                 out = hi == cnt ? end_all : __builtin_amdgcn_readlane(d0, (int)hi);
                 lo = hi;
+                SYT_ADD(4, tn0);
             }
+            SYT_ADD(1, tb0);
             return true;
         };
         auto park = [&](uint32_t tp, uint32_t flags, uint32_t kind, uint32_t dst, uint32_t a, uint32_t len) __attribute__((always_inline)) {
@@ -374,29 +425,55 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             }
             parked = true;
         };
-        // sequences the window parser leaves alone (lengths of KiB and more, the edges of the staged window): straight in HBM
+        // sequences the window parser leaves alone (literal runs that leave the staged window, lengths of KiB and more): the literals go
+        // from the stream straight to HBM -- nothing has to be waited for: they read the stream and write bytes nobody has written -- and
+        // a match that fits into the image is then decoded through it like any other, with the end of those literals as its history
+        // (read from the stream again, all values).  Incompressible data is made of such sequences (a literal run of KiB, a 4-byte match):
+        // with a fence before and after each of them pass A took 6 ms per GiB of it.
         auto single = [&](uint32_t tp, uint32_t ls, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t tok) __attribute__((always_inline)) -> bool {
             if (mlen == 0u && (tok & 15u) != 0u) { bad = true; return false; }        // the input ends after literals but a match was announced
             if ((uint64_t)lit + mlen > limit - out) { bad = true; return false; }
+            const unsigned long long tg0 = SYT_NOW();
             flush();
-            sy_sync(); unsynced = false;
             const uint32_t have = (tp == rtp) ? (st >> 1) : 0u;                 // what earlier launches did of this token
+            const uint32_t md = out + lit;
             if (lit && !(have & 1u)) {
                 if (lit >= SY_BIG && !last) { park(tp, 2u, 0u, out, ls, lit); return false; }
                 sy_lits_wave<SYM>(D, S, out, src + ls, lit, lane);
+                unsynced = true;
             }
-            const uint32_t md = out + lit;
             if (mlen && !(have & 2u)) {
                 if (off == 0u || off > md - base) { bad = true; return false; }
                 if (mlen >= SY_BIG && !last) { park(tp, 2u | 4u, 1u, md, off, mlen); return false; }
-                sy_sync();
+                if (mlen <= SY_IMG - SY_HIST) {
+                    const uint32_t K = lit < SY_HIST ? lit : SY_HIST;
+                    const uint8_t *g = src + ls + (lit - K);
+                    wave_sync();
+                    if (K < 16u) { if ((uint32_t)lane < K) { s_d[lane] = g[lane]; if (SYM) s_s[lane] = 0; } }
+                    else for (uint32_t i = (uint32_t)lane * 16u; i < K; i += 1024u) {
+                        const uint32_t j = i + 16u <= K ? i : K - 16u;
+                        u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
+                        ((hb_u128u *)(s_d + j))->v = ld16u(g + j);
+                        if (SYM) { ((hb_u128u *)((uint8_t *)s_s + 2u * j))->v = z; ((hb_u128u *)((uint8_t *)s_s + 2u * j + 16u))->v = z; }
+                    }
+                    wave_sync();
+                    ib = md - K; fl = md; out = md;
+                    SYT_ADD(7, tg0);
+                    return batch(1u, tp, md, 0u, mlen, off, 0u);
+                }
+                sy_sync(); unsynced = false;
                 sy_match_wave<SYM>(D, S, md, off, mlen, O, lane);
             }
             out = md + mlen; ib = out; fl = out;
-            sy_sync();
+            unsynced = true;
+            SYT_ADD(7, tg0);
             return true;
         };
-        const bool ok = rg_walk(src, n_src, start, exitp, s_win, s_tq, lane, batch, single);
+        const bool ok = rg_walk<PWIN>(src, n_src, start, exitp, s_win, s_tq, lane, batch, single);
         if (!parked) flush();
+#ifdef SY_DEBUG_TIMES
+        dbg_t[0] = SYT_NOW() - dbg_t0;
+        if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&sy_dbg[k], dbg_t[k]);
+#endif
         return ok && !bad;
 }

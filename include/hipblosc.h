@@ -127,7 +127,8 @@ int hb_lz4_compress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
 /* async; d_index/index_bytes optional (NULL/0 -> serial single-wavefront decode).
  * All `_dev` entry points load with 16-byte vectors: a source buffer may be READ up to 15 bytes past its last byte
  * (never written), so it must not end exactly at the end of a device allocation's last page -- hipMalloc'd buffers
- * with >= 16 bytes of slack, or any sub-range of a larger allocation, are fine. */
+ * with >= 16 bytes of slack, or any sub-range of a larger allocation, are fine.
+ * Every `d_work` must be 256-byte aligned (what hipMalloc returns; HB_ERR_BAD_ARG otherwise): the workspaces hold 16-byte records. */
 int hb_lz4_decompress_dev(const void *d_src, size_t n, void *d_dst, size_t cap,
                           const void *d_index, size_t index_bytes,
                           void *d_work, size_t work_bytes, hb_result *d_result, void *stream);
