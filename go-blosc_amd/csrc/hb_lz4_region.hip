@@ -649,7 +649,7 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
             if (steps > 1024u) { bad = true; break; }                   // (a bucket holds <= 512 stream bytes of token starts: cannot happen on the chain)
             // somebody found a unit boundary inside a match: there will be no index, stop walking (another writer's frame says so within
             // microseconds, and every lane of the launch would otherwise finish its bucket first)
-            if ((steps & 15u) == 15u && __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = true; break; }
+            if ((steps & 3u) == 3u && __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = true; break; }
             const uint32_t tp = (uint32_t)q;
             const uint32_t w = rg_rd4(src, n_src, q);
             const uint32_t tok = w & 255u;
@@ -684,7 +684,10 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
                 U += (g0 + ll - 1u - U) / HB_CHUNK * HB_CHUNK + HB_CHUNK;                // the first boundary at or behind the end of the run
             } else
                 for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
-            if (U < g0 + ll + ml && U < N) { bad = true; inmatch = true; break; }   // a unit boundary inside a match: the block was not written chunk-locally
+            if (U < g0 + ll + ml && U < N) {                            // a unit boundary inside a match: the block was not written chunk-locally
+                // (said at once: the other lanes of this wavefront, and every other wavefront of the launch, are still walking and poll the flag)
+                bad = true; inmatch = true; atomicExch(&plan->fail, 1u); break;
+            }
             d0 += ll + ml;
         }
         if (!bad && (q != send || (uint32_t)d0 != s_tr[k + 1].y)) bad = true;           // my walk must land on the next record exactly

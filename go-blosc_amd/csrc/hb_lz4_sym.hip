@@ -148,27 +148,41 @@ __global__ __launch_bounds__(64) void k_sy_units(const RgPlan *rg, const RgRegio
 
 // the units that have output, in order: all later kernels walk this list (most slots of `un` are empty)
 __global__ __launch_bounds__(1024) void k_sy_compact(SyPlan *sy, const SyUnit *__restrict__ un, uint32_t *__restrict__ list) {
-    __shared__ uint32_t s[1024];
+    // sixteen wavefronts, each over a contiguous 1/16 of the slots, 64 slots (2 KiB, coalesced) per step: the occupancy masks stay in LDS and
+    // the list is written from them (one read pass; a thread per 128 slots read them twice at a stride of 4 KiB: 0.17 ms)
+    constexpr uint32_t SPAN = SY_MAXUNITS / 16, STEPS = SPAN / 64;
+    __shared__ unsigned long long s_m[16][STEPS];
+    __shared__ uint32_t s_c[16];
     if (!sy->go) return;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const uint32_t nu = sy->nunits;
-    constexpr uint32_t PER = SY_MAXUNITS / 1024;
+    const uint32_t r0 = (uint32_t)w * SPAN;
+    const uint32_t steps = r0 >= nu ? 0u : ((nu - r0 < SPAN ? nu - r0 : SPAN) + 63u) / 64u;
     uint32_t cnt = 0;
-    for (uint32_t k = 0; k < PER; k++) { const uint32_t r = (uint32_t)t * PER + k; if (r < nu && un[r].outlen != 0u) cnt++; }
-    s[t] = cnt;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t y = t >= d ? s[t - d] : 0u;
-        __syncthreads();
-        s[t] += y;
-        __syncthreads();
+    for (uint32_t i = 0; i < steps; i += 8u) {                        // eight loads in flight (STEPS is a multiple of 8)
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) { const uint32_t r = r0 + (i + q) * 64u + (uint32_t)lane; v[q] = (i + q < steps && r < nu) ? un[r].outlen : 0u; }
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) {
+            const unsigned long long m = hb_ballot(v[q] != 0u);
+            if (lane == 0) s_m[w][i + q] = m;
+            cnt += (uint32_t)__builtin_popcountll(m);
+        }
     }
-    uint32_t o = s[t] - cnt;
-    for (uint32_t k = 0; k < PER; k++) { const uint32_t r = (uint32_t)t * PER + k; if (r < nu && un[r].outlen != 0u) list[o++] = r; }
-    if (t == 1023) {
-        const uint32_t n = s[1023], g = sy->groups;
-        sy->nact = n;
-        sy->per = n ? (n + g - 1u) / g : 1u;
+    if (lane == 0) s_c[w] = cnt;
+    __syncthreads();
+    uint32_t o = 0, total = 0;
+    for (int k = 0; k < 16; k++) { const uint32_t c = s_c[k]; if (k < w) o += c; total += c; }
+    for (uint32_t i = 0; i < steps; i++) {
+        const unsigned long long m = s_m[w][i];
+        if ((m >> lane) & 1ull) list[o + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = r0 + i * 64u + (uint32_t)lane;
+        o += (uint32_t)__builtin_popcountll(m);
+    }
+    if (t == 0) {
+        const uint32_t g = sy->groups;
+        sy->nact = total;
+        sy->per = total ? (total + g - 1u) / g : 1u;
     }
 }
 
@@ -389,37 +403,40 @@ __global__ __launch_bounds__(1024) void k_sy_tails(const SyUnit *__restrict__ un
     }
 }
 
+__global__ __launch_bounds__(1024) void k_sy_items(const SyUnit *__restrict__ un, const uint32_t *__restrict__ list, const SyPlan *sy, uint32_t *itembase) {
+    // itembase[r] = pieces of the units in front of list[r]; sixteen wavefronts, each a running sum over a contiguous 1/16 of the list
+    // (64 entries per step), then everybody adds what the wavefronts in front of it counted
+    constexpr uint32_t SPAN = SY_MAXUNITS / 16;
+    __shared__ uint32_t s_c[16];
+    if (!sy->go || sy->fail) return;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const uint32_t nreg = sy->nact;
+    const uint32_t r0 = (uint32_t)w * SPAN;
+    const uint32_t steps = r0 >= nreg ? 0u : ((nreg - r0 < SPAN ? nreg - r0 : SPAN) + 63u) / 64u;
+    uint32_t carry = 0;
+    for (uint32_t i = 0; i < steps; i += 4u) {                        // four gathers in flight
+        uint32_t Lq[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) { const uint32_t r = r0 + (i + q) * 64u + (uint32_t)lane; Lq[q] = (i + q < steps && r < nreg) ? un[list[r]].outlen : 0u; }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) {
+            const uint32_t r = r0 + (i + q) * 64u + (uint32_t)lane;
+            const uint32_t mine = Lq[q] > SY_W ? (Lq[q] - SY_W + SY_PIECE - 1u) / SY_PIECE : 0u;
+            const uint32_t incl = wave_incl_scan_dpp(mine);
+            if (i + q < steps && r < nreg) itembase[r] = carry + incl - mine;
+            carry += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+        }
+    }
+    if (lane == 0) s_c[w] = carry;
+    __syncthreads();
+    uint32_t o = 0, total = 0;
+    for (int k = 0; k < 16; k++) { const uint32_t c = s_c[k]; if (k < w) o += c; total += c; }
+    if (o) for (uint32_t i = 0; i < steps; i++) { const uint32_t r = r0 + i * 64u + (uint32_t)lane; if (r < nreg) itembase[r] += o; }
+    if (t == 0) itembase[SY_MAXUNITS] = total;
+}
+
 // what is left: the part of every region in front of its last 64 KiB, in pieces of SY_PIECE bytes over the whole chip.  Everything a
 // piece can name is final by now (tails of earlier regions), so the 64 KiB in front of its region are simply read back.
-__global__ __launch_bounds__(1024) void k_sy_items(const SyUnit *__restrict__ un, const uint32_t *__restrict__ list, const SyPlan *sy, uint32_t *itembase) {
-    __shared__ uint32_t s[1024];
-    if (!sy->go || sy->fail) return;
-    const int t = threadIdx.x;
-    const uint32_t nreg = sy->nact;
-    constexpr uint32_t PER = SY_MAXUNITS / 1024;
-    uint32_t mine[PER], sum = 0;
-    for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t r = (uint32_t)t * PER + k;
-        const uint32_t L = r < nreg ? un[list[r]].outlen : 0u;
-        mine[k] = L > SY_W ? (L - SY_W + SY_PIECE - 1u) / SY_PIECE : 0u;
-        sum += mine[k];
-    }
-    s[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t y = t >= d ? s[t - d] : 0u;
-        __syncthreads();
-        s[t] += y;
-        __syncthreads();
-    }
-    uint32_t o = s[t] - sum;
-    for (uint32_t k = 0; k < PER; k++) {
-        const uint32_t r = (uint32_t)t * PER + k;
-        if (r < nreg) itembase[r] = o;
-        o += mine[k];
-    }
-    if (t == 1023) itembase[SY_MAXUNITS] = s[1023];
-}
 __global__ __launch_bounds__(512) void k_sy_resolve(const SyUnit *__restrict__ un, const uint32_t *__restrict__ list, const SyPlan *sy, uint8_t *D, const uint16_t *__restrict__ S,
                                                     const uint32_t *__restrict__ itembase) {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[SY_W];

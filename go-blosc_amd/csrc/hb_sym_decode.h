@@ -473,7 +473,13 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
         if (!parked) flush();
 #ifdef SY_DEBUG_TIMES
         dbg_t[0] = SYT_NOW() - dbg_t0;
-        if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&sy_dbg[k], dbg_t[k]);
+        if (lane == 0) {
+            for (int k = 0; k < 16; k++) atomicAdd(&sy_dbg[k], dbg_t[k]);
+            int hb = 63 - __builtin_clzll(dbg_t[0] | 1ull) - 12;           // histogram of unit times: bin b = [2^(b+12), 2^(b+13)) clocks
+            hb = hb < 0 ? 0 : (hb > 14 ? 14 : hb);
+            atomicAdd(&sy_dbg[16 + hb], 1ull);
+            atomicMax(&sy_dbg[31], dbg_t[0]);
+        }
 #endif
         return ok && !bad;
 }
