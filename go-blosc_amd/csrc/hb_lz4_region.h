@@ -10,6 +10,8 @@
 #define RG_INVALID  0xFFFFFFFFu
 #define RG_MAXREG   16384u
 #define RG_MINREG   8192u         // smallest region, stream bytes (a region is one wavefront's serial walk: ~30 us per KiB -- small frames want small regions)
+#define RG_MINREG_SHORT 4096u     // ... of a stream of at most RG_SHORT bytes (1 - 16 MiB frames: 10-30 % less time; 2048: worse again, and 64 MiB frames lose with 4096)
+#define RG_SHORT    (8u << 20)
 #define RG_PWIN     4096u         // parse window: every kernel that walks tokens is bound by one wavefront's latency, so its throughput is the number
                                   // of resident waves -- 4 KiB gives k_rg_parse / k_rg_index 32 per CU (8 KiB: 17; index-less 1 GiB decode 5.1 -> 4.6 ms)
 #define RG_FIXROUNDS 16            // k_rg_settle launches (each iterates to a standstill; idle once settled), re-parses in between
@@ -31,13 +33,20 @@ struct __attribute__((aligned(16))) RgRegion {
 };
 struct RgPlan { uint32_t ok, fail, nreg, rs; uint64_t total; uint32_t pad[10]; };
 
+// the most regions a block that decodes to at most n_out bytes can have (rg_regions below)
+static inline size_t rg_max_regions(size_t n_out) {
+    const size_t bound = n_out + n_out / 255 + 16;
+    size_t nr = bound / RG_MINREG + 2;
+    const size_t ns = (bound < RG_SHORT ? bound : RG_SHORT) / RG_MINREG_SHORT + 2;
+    if (ns > nr) nr = ns;
+    return nr > RG_MAXREG ? RG_MAXREG : nr;
+}
 struct RgLayout { size_t plan, reg, pmax, trace, total; };
 // sized for the regions a block that decodes to at most n_out bytes can have (a stream is never much longer than its output)
 static inline RgLayout rg_layout(size_t n_out) {
     RgLayout L; size_t o = 0;
     auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
-    size_t nr = (n_out + n_out / 255 + 16) / RG_MINREG + 2;
-    if (nr > RG_MAXREG) nr = RG_MAXREG;
+    const size_t nr = rg_max_regions(n_out);
     L.plan = take(sizeof(RgPlan));
     L.reg = take(nr * sizeof(RgRegion));
     L.pmax = take(nr * 4);
@@ -140,7 +149,8 @@ __device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, 
 // 256 MiB in 1.7 instead of 2.4).
 static inline void rg_regions(size_t n, uint64_t *rs_out, uint32_t *nreg_out) {
     uint64_t rs = (n + RG_MAXREG - 1) / RG_MAXREG;
-    if (rs < RG_MINREG) rs = RG_MINREG;
+    const uint64_t lo = n <= RG_SHORT ? RG_MINREG_SHORT : RG_MINREG;
+    if (rs < lo) rs = lo;
     rs = (rs + 15) & ~(uint64_t)15;
     *rs_out = rs; *nreg_out = (uint32_t)((n + rs - 1) / rs);
 }

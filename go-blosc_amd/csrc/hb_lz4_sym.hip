@@ -62,7 +62,7 @@ struct SyLayout { size_t plan, par, units, list, big, items, sym, maps, tails, t
 static inline uint32_t sy_max_groups(size_t n_out) {
     // a group costs 512 KiB of map buffers: at most one per sixteen regions of the longest block n_out bytes can come from (a 1 MiB frame
     // then has 8 groups and 4 MiB of maps, not 256 and 128 MiB)
-    const size_t g = (hb_lz4_bound(n_out) / RG_MINREG + 1) / 16;
+    const size_t g = (rg_max_regions(n_out) + 15) / 16;
     return (uint32_t)(g < 1 ? 1 : (g < SY_GROUPS ? g : SY_GROUPS));
 }
 static inline SyLayout sy_layout(size_t n_out) {

@@ -85,7 +85,8 @@ def main():
             print(f"  r{i}: b {b[i]} entry {entry[i]} exit {exit_[i]} outlen {outlen[i]} | entry0 {entry0[i]} exit0 {exit0[i]} outlen0 {outlen0[i]} ntrace {ntrace[i]} needfull {needfull[i]} pad0 {regs[i, 9]}")
     # k_rg_index_fast's verdict per region (round 3): the done[] words live where k_rg_pmax's scratch was (RgLayout.pmax)
     al = lambda v: (v + 255) & ~255
-    nr_cap = min((n + n // 255 + 16) // 8192 + 2, RG_MAXREG)
+    bound = n + n // 255 + 16
+    nr_cap = min(max(bound // 8192 + 2, min(bound, 8 << 20) // 4096 + 2), RG_MAXREG)      # rg_max_regions (csrc/hb_lz4_region.h)
     off_pmax = base + al(64) + al(nr_cap * REG_BYTES)
     done = w[off_pmax: off_pmax + 4 * nreg].view(np.uint32)
     pad0 = regs[:, 9]
