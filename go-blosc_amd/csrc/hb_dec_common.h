@@ -38,7 +38,9 @@ struct DecBatchFrame {
 size_t hb_lz4_dec_batch_units(int nframes, const DecBatchFrame *h, uint32_t *unit0_out);
 int hb_launch_lz4_decode_batch_indexed(int nframes, const DecBatchFrame *d_bf, uint32_t *d_unit_frame, uint32_t total_units, int any_ush, hipStream_t s);
 
+#ifndef DTQ
 #define DTQ 96                           // token queue slots: < 64 queued before a window is parsed; a 64-byte window adds <= 22 LZ4 tokens or <= 32 Snappy elements
+#endif
 
 #define DLITCAP 16u
 #define DMCAP 32u             // matches up to this long are copied by their own lane

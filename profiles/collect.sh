@@ -19,6 +19,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/reftrace -- python3 $
 cp $(ls $O/reftrace/*/*kernel_stats.csv | head -1) $O/reference_frame_kernel_stats.csv || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/owntrace -- python3 $R/tools/region_debug.py --mib 1024 --dataset f32 --reps 5 --writer device > $O/owntrace.log 2>&1 || true
 cp $(ls $O/owntrace/*/*kernel_stats.csv | head -1) $O/indexless_frame_kernel_stats.csv || true
+# SQ counters of the same reference-written frame's decode (token discovery k_rg_*, symbolic decode k_sy_*): instruction mix, waits, waves
+A="$R/tools/region_debug.py --mib 1024 --dataset f32 --reps 2"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY --output-format csv -d $O/refsq -- python3 $A > $O/refsq.log 2>&1 || true
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $O/refsq2 -- python3 $A > $O/refsq2.log 2>&1 || true
+(cd $R && python3 profiles/summarize.py counters $O/refsq $O/reference_frame_sq.csv && python3 profiles/summarize.py counters $O/refsq2 $O/reference_frame_sq2.csv) || true
 # everything bench.py measures beside the headline (configs 3 / 4 / 5, index-less and reference-written decodes, C-Blosc-1 frames, the
 # small-frame batches): one kernel trace of a short full run
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/alltrace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-multi > $O/alltrace.log 2>&1 || true
