@@ -636,11 +636,9 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
     wave_sync();
     const uint32_t headend = s_tr[0].x;
     bool bad = false, inmatch = false;
-    // a literal run with many unit boundaries in it (an incompressible byte plane is ONE run of 256 MiB: 65536 entries) is left to the
-    // whole wave, below: written by the one lane that came across it, those entries were half of this launch
-    bool hasbig = false;
-    uint64_t bigU = 0, bigG0 = 0, bigEnd = 0;
-    uint32_t bigLs = 0, bigTp = 0;
+    // (Measured and not kept, round 3: a 16-byte register window per lane so that 3-4 byte sequences share a memory round trip -- no gain, the
+    // walk is bound by its dependent steps, not by the loads' count; the whole wavefront emitting the entries of a long literal run -- the
+    // lanes' extra state cost the launch 0.14 ms, and runs of more than 64 KiB never get here.)
     for (uint32_t k = (uint32_t)lane; k < nu; k += 64u) {
         const uint32_t send = s_tr[k + 1].x;                            // my segment: the tokens that START in [s_tr[k].x, send)
         uint64_t q = s_tr[k].x;                                         // stream position
@@ -649,10 +647,14 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
             if (steps > 1024u) { bad = true; break; }                   // (a bucket holds <= 512 stream bytes of token starts: cannot happen on the chain)
             // somebody found a unit boundary inside a match: there will be no index, stop walking (another writer's frame says so within
             // microseconds, and every lane of the launch would otherwise finish its bucket first)
-            if ((steps & 3u) == 3u && __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bad = true; break; }
+            // (the poll is ISSUED in front of the token's read and LOOKED AT behind it: both are in flight together and return in order, so the
+            // step waits once; a poll that is branched on at once adds a memory round trip to every polling step: +20 % for a frame that has an index)
+            uint32_t failseen = 0;
+            if ((steps & 3u) == 3u) failseen = __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t tp = (uint32_t)q;
             const uint32_t w = rg_rd4(src, n_src, q);
             const uint32_t tok = w & 255u;
+            if (failseen) { bad = true; break; }
             uint64_t ll = tok >> 4;
             q++;
             if (ll == 15u) {
@@ -679,14 +681,13 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
             const uint64_t g0 = opos + d0;                              // absolute output position of the sequence
             uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
             if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
-            if (!hasbig && U + 8u * HB_CHUNK < g0 + ll) {
-                hasbig = true; bigU = U; bigG0 = g0; bigEnd = g0 + ll; bigLs = (uint32_t)ls; bigTp = tp;
-                U += (g0 + ll - 1u - U) / HB_CHUNK * HB_CHUNK + HB_CHUNK;                // the first boundary at or behind the end of the run
-            } else
-                for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
+            for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
             if (U < g0 + ll + ml && U < N) {                            // a unit boundary inside a match: the block was not written chunk-locally
                 // (said at once: the other lanes of this wavefront, and every other wavefront of the launch, are still walking and poll the flag)
-                bad = true; inmatch = true; atomicExch(&plan->fail, 1u); break;
+                // (one writer is enough: 100 000 lanes of a foreign frame get here, and as many atomics on one word take milliseconds)
+                bad = true; inmatch = true;
+                if (!__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicExch(&plan->fail, 1u);
+                break;
             }
             d0 += ll + ml;
         }
@@ -700,15 +701,6 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
     // anything odd: the wave walk does the whole region again, with the machinery the other decoders share (it also decides what a
     // boundary inside a match means for the frame)
     if (hb_ballot(bad)) { if (lane == 0) done[r] = 6u; return; }
-    for (unsigned long long bm = hb_ballot(hasbig); bm; bm &= bm - 1ull) {
-        const int l = __builtin_ctzll(bm);
-        const uint64_t U0 = (uint64_t)__builtin_amdgcn_readlane((uint32_t)bigU, l) | ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bigU >> 32), l) << 32);
-        const uint64_t G0 = (uint64_t)__builtin_amdgcn_readlane((uint32_t)bigG0, l) | ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bigG0 >> 32), l) << 32);
-        uint64_t E = (uint64_t)__builtin_amdgcn_readlane((uint32_t)bigEnd, l) | ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bigEnd >> 32), l) << 32);
-        const uint32_t Ls = __builtin_amdgcn_readlane(bigLs, l), Tp = __builtin_amdgcn_readlane(bigTp, l);
-        const uint64_t lim = E < N ? E : N;
-        for (uint64_t U = U0 + (uint64_t)lane * HB_CHUNK; U < lim; U += 64ull * HB_CHUNK) rg_emit(ents, U, (uint32_t)(Ls + (U - G0)), (uint32_t)(E - U), Tp);
-    }
     if (lane == 0) done[r] = headend;                                   // the head [entry, first usable record) is still to do
 }
 

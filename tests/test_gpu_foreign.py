@@ -120,6 +120,10 @@ def test_foreign_frames_need_the_larger_workspace(hb, O):
             assert int(res[:4].view(np.int32)[0]) == 0
             assert int(res[4:8].view(np.uint32)[0]) & 1 == want_flag
             assert np.array_equal(back, x)
+        # the workspace must be 256-byte aligned (include/hipblosc.h: its records are read and written with 16-byte vectors): refused, nothing launched
+        HB_ERR_BAD_ARG = -11
+        odd = ctypes.c_void_p(d_work.value + 8)
+        assert L.hb_decompress_frame_dev(d_frame, f.size, d_out, n, 0, odd, large - 8, d_res, None) == HB_ERR_BAD_ARG
     finally:
         for ptr in (d_frame, d_out, d_res, d_work):
             hip.hipFree(ptr)
