@@ -42,18 +42,20 @@
 #endif
 #include "hb_sym_decode.h"
 #ifdef SY_DEBUG_TIMES
-__device__ unsigned long long sy_dbg[32];
+__device__ unsigned long long sy_dbg[48];
 extern "C" void hb_debug_sy_times(unsigned long long *out, int reset) {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sy_dbg), sizeof(unsigned long long) * 32);
-    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sy_dbg), z, sizeof z); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sy_dbg), sizeof(unsigned long long) * 48);
+    if (reset) { unsigned long long z[48] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sy_dbg), z, sizeof z); }
 }
 #endif
 
 #define SY_W        65536u        // entries of a tail map / bytes of a tail image (index = distance 1..65535; entry 0 unused)
 #define SY_GROUPS   256u          // groups of units in pass B (128: k_sy_compose 1.9 ms, 256: 1.05, 512: 1.0 but the scan over the groups 0.4)
 #define SY_SUB      8u            // a region with more than SY_HEAVY bytes of output is decoded in this many parts
+#ifndef SY_HEAVY
 #define SY_HEAVY    (256u << 10)  // (1 MiB until regions went down to 8 KiB: a short frame's 100:1 plane then sat in a few 800 KiB units -- 4 MiB frame 2.9 -> 1.8 ms)
+#endif
 #define SY_MAXUNITS (RG_MAXREG * SY_SUB)
 #define SY_PIECE    (256u << 10)  // bytes of a region one workgroup resolves at a time (k_sy_resolve)
 #define SY_ROUNDS   3             // launches of pass A; the last one copies everything inline
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(64) void k_sy_units(const RgPlan *rg, const RgRegio
         if ((uint32_t)lane < SY_SUB) {
             SyUnit x;
             x.entry = s_e[lane]; x.exit = s_e[lane + 1]; x.opos = s_o[lane]; x.outlen = s_o[lane + 1] - s_o[lane];
-            x.rtp = 0; x.rout = 0; x.state = 0; x.pad = 0;
+            x.rtp = 0; x.rout = 0; x.state = 0; x.plit = 0; x.pmlen = 0; x.poff = 0; x.pnext = 0; x.pad = 0;
             u[lane] = x;
         }
     }
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(1024) void k_sy_compact(SyPlan *sy, const SyUnit *_
 // ---- pass A ----
 // A literal run or a match of SY_BIG bytes and more is not for one wavefront (2-3 GB/s): the region posts it, stops in front of it
 // and is resumed by the next launch, after k_sy_big has done all posted copies with the whole chip.  The LAST launch copies inline.
-// Unit state between launches (SyUnit): rtp = stream position of the token to resume at (0: not started), rout = output position
-// there, state bit 0 = unit done, bit 1 = that token's literals are copied, bit 2 = its match too.
+// Unit state between launches (SyUnit): rtp = stream position of the token to resume at, rout = output position there, state bit 0 = unit
+// done, bit 1 = the literal run of the token at rtp was posted (the rest of that sequence is on record and is not parsed again).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SY_WAVES))) void k_sy_decode(const uint8_t *__restrict__ src, uint64_t n_src, SyUnit *un, const uint32_t *__restrict__ list,
                                                    SyPlan *sy, SyBig *big, uint8_t *D, uint16_t *S, int last) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[SY_PWIN + 128];
@@ -208,8 +210,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SY_WAVES))) 
         if (st & 1u) continue;
         const uint32_t O = RFL(R->opos);
         const uint32_t rtp = RFL(R->rtp);
-        const uint32_t start = rtp ? rtp : entry;
-        uint32_t out = rtp ? RFL(R->rout) : O;         // next output byte
+        const bool cont = rtp != 0u || (st & 2u) != 0u;                  // parked before (the block's first token is at position 0)
+        const uint32_t start = cont ? rtp : entry;
+        uint32_t out = cont ? RFL(R->rout) : O;        // next output byte
         bool parked;
         const bool ok = sy_decode_unit<true, SY_PWIN>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen));
         if (!parked) {

@@ -9,16 +9,21 @@
 #define SY_HIST     2048u
 #endif
 #define SY_NCAP     64u           // image-to-image copies up to this long are done by their own lane
+#ifndef SY_BIG
 #define SY_BIG      (256u << 10)  // literal runs / matches from this size on are copied by the whole chip (k_sy_big)
+#endif
 
 struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact; uint32_t pad[9]; };   // per: units WITH OUTPUT per group of pass B
 // what one wavefront of pass A decodes: a region of the token discovery, or one of SY_SUB parts of a region whose output is large
-struct SyUnit { uint32_t entry, exit, opos, outlen, rtp, rout, state, pad; };   // state: bit 0 done, bit 1 / 2: literals / match of token rtp copied
+// state: bit 0 done, bit 1: the literal run of the token at rtp is being / has been copied by k_sy_big -- the rest of that sequence is on record
+// (plit / pmlen / poff, pnext = the token behind it): a resumed unit never parses a parked token again (the length extension of a 256 MiB run is a
+// MiB of FF bytes).  A parked MATCH leaves no token behind: rtp = the next token, rout = the output position behind the match, state 0.
+struct SyUnit { uint32_t entry, exit, opos, outlen, rtp, rout, state, plit, pmlen, poff, pnext, pad; };
 struct SyBig { uint32_t kind, dst, src, len, O, pad[3]; };          // kind 0: literals from stream position src; 1: match, src = offset
 
 #ifdef SY_DEBUG_TIMES
 // phase clocks of pass A (build variant only: scratch/mkvariant.sh sytimes hb_lz4_sym.hip -DSY_DEBUG_TIMES; read by hb_debug_sy_times)
-extern __device__ unsigned long long sy_dbg[32];
+extern __device__ unsigned long long sy_dbg[48];
 #define SYT_NOW() __builtin_readcyclecounter()
 #define SYT_ADD(slot, t0) do { dbg_t[slot] += SYT_NOW() - (t0); } while (0)
 #define SYT_CNT(slot) do { dbg_t[slot] += 1ull; } while (0)
@@ -263,6 +268,7 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
                                                const uint32_t limit) {
         uint8_t *Sb = (uint8_t *)S;
         parked = false;
+        const bool resumed = SYM && R != nullptr && (st & 2u) != 0u;             // behind a literal run k_sy_big copied (see SyUnit)
 #ifdef SY_DEBUG_TIMES
         unsigned long long dbg_t[16] = {0};
         const unsigned long long dbg_t0 = SYT_NOW();
@@ -416,12 +422,18 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             SYT_ADD(1, tb0);
             return true;
         };
-        auto park = [&](uint32_t tp, uint32_t flags, uint32_t kind, uint32_t dst, uint32_t a, uint32_t len) __attribute__((always_inline)) {
+        // kind 0: the literal run [ls, ls + lit) of the sequence at tp to out; the rest of the sequence (mlen at distance off, then the token at
+        // pnext) goes on record.  kind 1: the match of mlen bytes at distance off to md; the unit resumes at the token pnext with output md + mlen.
+        auto park = [&](uint32_t tp, uint32_t kind, uint32_t dst, uint32_t a, uint32_t len, uint32_t lit, uint32_t mlen, uint32_t off, uint32_t pnext) __attribute__((always_inline)) {
+#ifdef SY_DEBUG_TIMES
+            if (lane == 0) { atomicAdd(&sy_dbg[32 + kind], 1ull); atomicAdd(&sy_dbg[34 + kind], (unsigned long long)(len >> 10)); }
+#endif
             if (lane == 0) {
                 const uint32_t slot = atomicAdd(&sy->nbig, 1u);             // (at most one per region and launch: nreg slots)
                 SyBig b; b.kind = kind; b.dst = dst; b.src = a; b.len = len; b.O = O; b.pad[0] = b.pad[1] = b.pad[2] = 0;
                 big[slot] = b;
-                R->rtp = tp; R->rout = out; R->state = flags;
+                if (kind == 0u) { R->rtp = tp; R->rout = out; R->state = 2u; R->plit = lit; R->pmlen = mlen; R->poff = off; R->pnext = pnext; }
+                else { R->rtp = pnext; R->rout = dst + len; R->state = 0u; R->plit = 0u; }
             }
             parked = true;
         };
@@ -435,16 +447,18 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             if ((uint64_t)lit + mlen > limit - out) { bad = true; return false; }
             const unsigned long long tg0 = SYT_NOW();
             flush();
-            const uint32_t have = (tp == rtp) ? (st >> 1) : 0u;                 // what earlier launches did of this token
+            const uint32_t have = (resumed && tp == rtp) ? 1u : 0u;             // the literal run of this token is in place (k_sy_big)
             const uint32_t md = out + lit;
+            // the token behind this sequence (LZ4's length code is unique: the number of extension bytes follows from the length)
+            const uint32_t pnext = ls + lit + (mlen ? 2u + (mlen >= 19u ? (mlen - 19u) / 255u + 1u : 0u) : 0u);
             if (lit && !(have & 1u)) {
-                if (lit >= SY_BIG && !last) { park(tp, 2u, 0u, out, ls, lit); return false; }
+                if (lit >= SY_BIG && !last) { park(tp, 0u, out, ls, lit, lit, mlen, off, pnext); return false; }
                 sy_lits_wave<SYM>(D, S, out, src + ls, lit, lane);
                 unsynced = true;
             }
-            if (mlen && !(have & 2u)) {
+            if (mlen) {
                 if (off == 0u || off > md - base) { bad = true; return false; }
-                if (mlen >= SY_BIG && !last) { park(tp, 2u | 4u, 1u, md, off, mlen); return false; }
+                if (mlen >= SY_BIG && !last) { park(tp, 1u, md, off, mlen, lit, mlen, off, pnext); return false; }
                 if (mlen <= SY_IMG - SY_HIST) {
                     const uint32_t K = lit < SY_HIST ? lit : SY_HIST;
                     const uint8_t *g = src + ls + (lit - K);
@@ -469,7 +483,19 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             SYT_ADD(7, tg0);
             return true;
         };
-        const bool ok = rg_walk<PWIN>(src, n_src, start, exitp, s_win, s_tq, lane, batch, single);
+        // Resuming behind a literal run k_sy_big has copied: the token is NOT parsed again -- the run in front of an incompressible byte plane is
+        // 256 MiB and more, its length extension a MiB of FF bytes that one wavefront reads at 4 KiB per memory round trip (0.3 ms for the headline
+        // frame, 1 ms for 850 MiB of random floats: that was the whole second launch of pass A, everybody else idle).  The whole sequence is on record
+        // (SyUnit), and the number of extension bytes follows from a length (LZ4's length code is unique).
+        uint32_t walk_from = start;
+        bool ok = true;
+        if (resumed) {
+            const uint32_t lit = RFL(R->plit), mlen = RFL(R->pmlen), off = RFL(R->poff);
+            const uint32_t ls = rtp + 1u + (lit >= 15u ? (lit - 15u) / 255u + 1u : 0u);
+            walk_from = RFL(R->pnext);
+            ok = single(rtp, ls, lit, mlen, off, mlen ? 0u : (uint32_t)src[rtp] & 0xF0u);
+        }
+        if (ok && !parked) ok = rg_walk<PWIN>(src, n_src, walk_from, exitp, s_win, s_tq, lane, batch, single);
         if (!parked) flush();
 #ifdef SY_DEBUG_TIMES
         dbg_t[0] = SYT_NOW() - dbg_t0;
@@ -479,6 +505,7 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             hb = hb < 0 ? 0 : (hb > 14 ? 14 : hb);
             atomicAdd(&sy_dbg[16 + hb], 1ull);
             atomicMax(&sy_dbg[31], dbg_t[0]);
+            if (rtp) { atomicAdd(&sy_dbg[36], 1ull); atomicAdd(&sy_dbg[37], dbg_t[0]); atomicMax(&sy_dbg[38], dbg_t[0]); atomicAdd(&sy_dbg[39], dbg_t[8]); }
         }
 #endif
         return ok && !bad;
