@@ -85,10 +85,38 @@ static inline SyLayout sy_layout(size_t n_out) {
 }
 size_t hb_lz4_sym_workspace(size_t n_out) { return sy_layout(n_out).total; }
 
+// wavefronts of pass A the current device holds at a time: CUs x (LDS per CU / LDS per wavefront), at most SY_WAVES per SIMD
+static uint32_t hb_sy_slots() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t lds = (uint32_t)(SY_PWIN + 128 + DTQ * 8 + (SY_IMG + 64) * 3);
+    uint32_t per_cu = (160u << 10) / ((lds + 511u) & ~511u);
+    if (per_cu > 4u * SY_WAVES) per_cu = 4u * SY_WAVES;
+    return (uint32_t)cus * per_cu;
+}
+
 // go: the token chain is verified and nothing has decoded the block yet
-__global__ void k_sy_gate(const RgPlan *rg, const DecPlan *dp, SyPlan *sy, uint32_t groups, uint32_t per) {
-    sy->go = (rg->ok && !(dp->mode == DEC_INDEXED && !dp->fail)) ? 1u : 0u;
-    sy->fail = 0; sy->groups = groups; sy->per = per; sy->nbig = 0; sy->nunits = rg->nreg * SY_SUB;
+// ... and how many regions have output at all.  Pass A is a set of independent latency chains, one per unit, and `slots` wavefronts of it are
+// resident at a time; pass B pays ~0.2 us per unit (k_sy_compose).  So the units should about fill the chip ONCE: two light neighbours share a
+// unit only while that leaves at least 3/4 of the slots with a unit each (the headline frame as the reference writes it: 6876 regions -> 4025
+// units on 4352 slots; random floats have 2860 token-dense regions behind three incompressible planes: merged into 879 units they kept a fifth
+// of the chip busy for 5.3 ms, unmerged 2.0 ms).
+__global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegion *__restrict__ reg, const DecPlan *dp, SyPlan *sy, uint32_t groups, uint32_t per, uint32_t slots) {
+    __shared__ uint32_t s_n[16];
+    const int t = threadIdx.x;
+    const uint32_t go = (rg->ok && !(dp->mode == DEC_INDEXED && !dp->fail)) ? 1u : 0u;
+    uint32_t n = 0;
+    if (go) for (uint32_t r = t; r < rg->nreg; r += 1024u) n += reg[r].outlen != 0u ? 1u : 0u;
+    for (int d = 32; d; d >>= 1) n += (uint32_t)__shfl_down((int)n, d);
+    if ((t & 63) == 0) s_n[t >> 6] = n;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t live = 0;
+        for (int k = 0; k < 16; k++) live += s_n[k];
+        sy->go = go;
+        sy->fail = 0; sy->groups = groups; sy->per = per; sy->nbig = 0; sy->nunits = rg->nreg * SY_SUB;
+        sy->live = live; sy->merge = (uint64_t)live * 2u >= (uint64_t)slots * 3u ? 1u : 0u;     // live / 2 >= 3/4 slots
+    }
 }
 
 // ---- the units of pass A.  A region of the discovery is a fixed span of the STREAM; where the data compresses 100:1 that is tens of
@@ -108,7 +136,7 @@ __global__ __launch_bounds__(64) void k_sy_units(const RgPlan *rg, const RgRegio
         const uint32_t O = (uint32_t)R.opos;
         // two neighbouring light regions make ONE unit (the even one gets it, the odd one stays empty): the discovery likes its regions
         // small -- a region is one wavefront's serial parse -- but every unit costs pass B a 64 Ki-entry map (k_sy_compose)
-        if ((r ^ 1u) < nreg) {
+        if ((r ^ 1u) < nreg && sy->merge) {
             const uint32_t Lm = reg[r ^ 1u].outlen;
             if ((uint64_t)L + Lm <= SY_HEAVY) {
                 if (r & 1u) { entry = exitp; L = 0u; }
@@ -535,14 +563,14 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     SyBig *big = (SyBig *)(sym_work + L.big);
     uint32_t *list = (uint32_t *)(sym_work + L.list);
     hb_prof_begin("k_sy_units", s);
-    hipLaunchKernelGGL(k_sy_gate, dim3(1), dim3(1), 0, s, rg, dp, sy, groups, per);
+    hipLaunchKernelGGL(k_sy_gate, dim3(1), dim3(1024), 0, s, rg, (const RgRegion *)reg, dp, sy, groups, per, hb_sy_slots());
     hipLaunchKernelGGL(k_sy_units, dim3((nreg + 3) / 4), dim3(64), 0, s, rg, reg, (const uint2 *)(w + RL.trace), sy, un);
     hipLaunchKernelGGL(k_sy_compact, dim3(1), dim3(1024), 0, s, sy, un, list);
     hb_prof_end(s);
     for (int k = 0; k < SY_ROUNDS; k++) {
         const int last = k + 1 == SY_ROUNDS;
         hb_prof_begin("k_sy_decode", s);
-        hipLaunchKernelGGL(k_sy_decode, dim3(nunits < 4096u ? nunits : 4096u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last);
+        hipLaunchKernelGGL(k_sy_decode, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last);
         hb_prof_end(s);
         if (!last) {
             hb_prof_begin("k_sy_big", s);

@@ -13,7 +13,7 @@
 #define SY_BIG      (256u << 10)  // literal runs / matches from this size on are copied by the whole chip (k_sy_big)
 #endif
 
-struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact; uint32_t pad[9]; };   // per: units WITH OUTPUT per group of pass B
+struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact, live, merge; uint32_t pad[7]; };   // per: units WITH OUTPUT per group of pass B; live: regions with output; merge: light neighbours share a unit
 // what one wavefront of pass A decodes: a region of the token discovery, or one of SY_SUB parts of a region whose output is large
 // state: bit 0 done, bit 1: the literal run of the token at rtp is being / has been copied by k_sy_big -- the rest of that sequence is on record
 // (plit / pmlen / poff, pnext = the token behind it): a resumed unit never parses a parked token again (the length extension of a 256 MiB run is a
