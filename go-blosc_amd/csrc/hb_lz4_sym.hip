@@ -97,8 +97,8 @@ static uint32_t hb_sy_slots() {
 
 // go: the token chain is verified and nothing has decoded the block yet
 // ... and how many regions have output at all.  Pass A is a set of independent latency chains, one per unit, and `slots` wavefronts of it are
-// resident at a time; pass B pays ~0.2 us per unit (k_sy_compose).  So the units should about fill the chip ONCE: two light neighbours share a
-// unit only while that leaves at least 3/4 of the slots with a unit each (the headline frame as the reference writes it: 6876 regions -> 4025
+// resident at a time; pass B pays ~0.2 us per unit (k_sy_compose).  So the units should at least fill the chip once: two light neighbours
+// share a unit only while that leaves at least 3/4 of the slots with a unit each (the headline frame as the reference writes it: 6876 regions -> 4025
 // units on 4352 slots; random floats have 2860 token-dense regions behind three incompressible planes: merged into 879 units they kept a fifth
 // of the chip busy for 5.3 ms, unmerged 2.0 ms).
 __global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegion *__restrict__ reg, const DecPlan *dp, SyPlan *sy, uint32_t groups, uint32_t per, uint32_t slots) {
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegi
         for (int k = 0; k < 16; k++) live += s_n[k];
         sy->go = go;
         sy->fail = 0; sy->groups = groups; sy->per = per; sy->nbig = 0; sy->nunits = rg->nreg * SY_SUB;
-        sy->live = live; sy->merge = (uint64_t)live * 2u >= (uint64_t)slots * 3u ? 1u : 0u;     // live / 2 >= 3/4 slots
+        // merge level: groups of 2^merge neighbours share a unit; pairs while live / 2 >= 3/4 slots.  (Groups of four when that still fills the
+        // slots -- bit-shuffled data, 16378 token-dense regions -- were measured: k_sy_compose 1.35 -> 0.98 ms, but pass A 6.2 -> 9.2: one
+        // generation of long units ends with its slowest one, two generations of shorter ones are dealt out as slots come free.)
+        sy->live = live; sy->merge = (uint64_t)live * 2u >= (uint64_t)slots * 3u ? 1u : 0u;
     }
 }
 
@@ -136,11 +139,15 @@ __global__ __launch_bounds__(64) void k_sy_units(const RgPlan *rg, const RgRegio
         const uint32_t O = (uint32_t)R.opos;
         // two neighbouring light regions make ONE unit (the even one gets it, the odd one stays empty): the discovery likes its regions
         // small -- a region is one wavefront's serial parse -- but every unit costs pass B a 64 Ki-entry map (k_sy_compose)
-        if ((r ^ 1u) < nreg && sy->merge) {
-            const uint32_t Lm = reg[r ^ 1u].outlen;
-            if ((uint64_t)L + Lm <= SY_HEAVY) {
-                if (r & 1u) { entry = exitp; L = 0u; }
-                else { exitp = reg[r ^ 1u].exit; L += Lm; }
+        for (uint32_t m = sy->merge; m > 0u; m--) {                       // aligned groups of 4, else of 2 (k_sy_gate says how far to go)
+            const uint32_t w = 1u << m, g0 = r & ~(w - 1u);
+            if (g0 + w > nreg) continue;
+            uint64_t tot = 0;
+            for (uint32_t k = 0; k < w; k++) tot += reg[g0 + k].outlen;
+            if (tot <= SY_HEAVY) {
+                if (r != g0) { entry = exitp; L = 0u; }
+                else { exitp = reg[g0 + w - 1u].exit; L = (uint32_t)tot; }
+                break;
             }
         }
         SyUnit *u = un + (size_t)r * SY_SUB;
