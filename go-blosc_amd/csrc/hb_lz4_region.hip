@@ -779,6 +779,15 @@ __global__ void k_rg_index_head(RgPlan *plan, uint8_t *__restrict__ index, uint6
 
 // Builds the restart index of an index-less block in the workspace; *index / *index_bytes then go to k_dec_plan / k_dec_indexed as if
 // the frame had carried them (an index that could not be built stays zeroed and is rejected there: serial decode).
+// workgroups of the FIRST re-parse behind k_rg_fix: almost every region moved its entry off the guess then (14 500 of 16 378 on the headline
+// frames) and re-parses a few windows until it meets its own record; 1024 workgroups did 14 regions each, one after the other (0.34 -> 0.28 ms).
+// (Also measured in round 3 and not kept: a table of announced literal runs of >= 1 MiB, so that the first parse of the regions INSIDE such a run --
+// the incompressible plane of shuffled floats is a quarter to a half of all regions, and parsing its bytes as tokens costs what parsing tokens costs --
+// does not start or stops under way: the run's token is read late in ITS region's parse, the regions it covers are parsing at the same time, and
+// only the second generation of workgroups profits: k_rg_parse 1.88 -> 1.74 ms on the reference-written frame, nothing on this library's own.)
+#ifndef RG_FIXGRID
+#define RG_FIXGRID 16384u
+#endif
 int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size_t *index_bytes, hipStream_t s) {
     const RgLayout L = rg_layout(a.cap);
     uint8_t *w = a.work + 256;                                          // behind the DecPlan
@@ -797,7 +806,7 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     hb_prof_begin("k_rg_fix", s);
     hipLaunchKernelGGL(k_rg_pmax, dim3(1), dim3(1024), 0, s, plan, reg, (uint32_t *)(w + L.pmax));
     hipLaunchKernelGGL(k_rg_fix, dim3((nreg + 63) / 64), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, (const uint32_t *)(w + L.pmax));
-    hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
+    hipLaunchKernelGGL(k_rg_parse, dim3(nreg < RG_FIXGRID ? nreg : RG_FIXGRID), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
     hb_prof_end(s);
     hb_prof_begin("k_rg_settle", s);
     for (int k = 0; k < RG_FIXROUNDS; k++) {                           // (both return at once when an earlier round has settled the chain)
