@@ -41,6 +41,16 @@ static inline size_t rg_max_regions(size_t n_out) {
     if (ns > nr) nr = ns;
     return nr > RG_MAXREG ? RG_MAXREG : nr;
 }
+// bytes of token store for any block that decodes to at most n_out bytes
+static inline size_t rg_tok_bytes(size_t n_out) {
+    const size_t bound = n_out + n_out / 255 + 16;
+    return (bound / 3 + 80 * rg_max_regions(n_out) + 4096) * 8;
+}
+// ---- the token store (round 3).  Every stage behind the first parse used to walk the stream again; with room for it (the larger, "foreign"
+// workspace) k_rg_parse keeps what it parsed: {position, literal length | match length << 16} per token, RG region r's at tok[r * tokcap ...], their
+// number in RgRegion.pad1[0] (RG_INVALID: none / more than fit).  Like the bucket records they lie on the final chain from RgRegion.pad0 on, if the
+// recorded parse ends where the chain does (exit0 == exit).  A token whose lengths do not fit 16 bits is stored as {position, RG_INVALID}.
+static inline uint32_t rg_tokcap(uint64_t rs) { return (uint32_t)(rs / 3u + 64u); }     // (a sequence is at least 3 bytes)
 struct RgLayout { size_t plan, reg, pmax, trace, total; };
 // sized for the regions a block that decodes to at most n_out bytes can have (a stream is never much longer than its output)
 static inline RgLayout rg_layout(size_t n_out) {

@@ -50,21 +50,23 @@ __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t r
     if (r >= nreg) return;
     RgRegion R;
     R.b = r * rs; R.entry = R.b; R.exit = RG_INVALID; R.outlen = 0; R.entry0 = R.b; R.exit0 = RG_INVALID; R.outlen0 = 0; R.ntrace = 0;
-    R.needfull = 1; R.pad0 = R.b; R.opos = 0; R.pad1[0] = R.pad1[1] = R.pad1[2] = R.pad1[3] = 0;
+    R.needfull = 1; R.pad0 = R.b; R.opos = 0; R.pad1[0] = RG_INVALID; R.pad1[1] = R.pad1[2] = R.pad1[3] = 0;
     reg[r] = R;
 }
 
 // ---- (1a) parse a region from its entry to the first token at / after the next region's start; no copies ----
 // parses region r from its believed first token (reg[r].entry) to the first token at / after the next region's start; one wavefront.
 // first: nothing is on record yet.  s_win: RG_PWIN + 128 bytes, s_tq: DTQ entries, both this wave's own.
+// tok / tokcap: the token store (hb_lz4_region.h), or NULL.
 __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src, const uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, const uint32_t r,
-                                                const int first, uint8_t *s_win, uint2 *s_tq, const int lane) {
+                                                const int first, uint8_t *s_win, uint2 *s_tq, const int lane, uint2 *tok = nullptr, const uint32_t tokcap = 0) {
     const uint32_t nreg = plan->nreg;
     RgRegion *R = reg + r;
     {
         uint32_t start = RFL(R->entry);
         const uint64_t bnext = (r + 1 < nreg) ? (uint64_t)RFL(reg[r + 1].b) : n_src;
         uint2 *tr = traces + (size_t)r * RG_TRACE;
+        uint2 *const tk = tok ? tok + (size_t)r * tokcap : nullptr;
         const uint32_t rb = RFL(R->b), bsh = plan->pad[0];                 // bucket = (position - b) >> bsh
         // A region that was parsed before is re-parsed in MERGE mode: nothing is recorded, the first token of every bucket is compared
         // with the one on record, and at the first match the two parses have merged -- exit unchanged, output length corrected by the
@@ -215,6 +217,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                     uint2 t; t.x = (uint32_t)ap; t.y = (uint32_t)(out + incl - olen);
                     if (idx < RG_DENSE) tr[idx] = t;
                     if (bk != pbk && bk < RG_BUCKETS) tr[RG_DENSE + bk] = t;
+                    if (tk && idx < tokcap) { uint2 k; k.x = (uint32_t)ap; k.y = e.y; tk[idx] = k; }
                 }
                 if (cnt) lastbk = (uint32_t)__builtin_amdgcn_readlane(bk, (int)cnt - 1);
                 out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
@@ -268,6 +271,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                     uint2 t; t.x = tokstart; t.y = (uint32_t)out;
                     if (ntok < RG_DENSE) tr[ntok] = t;
                     if (bk != lastbk && bk < RG_BUCKETS) tr[RG_DENSE + bk] = t;
+                    if (tk && ntok < tokcap) { uint2 k; k.x = tokstart; k.y = (ll <= 0xFFFFu && ml <= 0xFFFFu) ? (ll | (ml << 16)) : RG_INVALID; tk[ntok] = k; }
                 }
                 lastbk = bk;
             }
@@ -285,6 +289,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 R->exit = ex; R->outlen = (uint32_t)out;
                 R->entry0 = start; R->exit0 = ex; R->outlen0 = (uint32_t)out; R->ntrace = ntok < RG_DENSE ? ntok : RG_DENSE;
                 R->pad0 = start;                                         // the whole record lies on this parse
+                R->pad1[0] = (tk && ntok <= tokcap && !invalid) ? ntok : RG_INVALID;
                 if (first) R->entry = start;                             // (the guess may have moved to a spotted token)
             }
             R->needfull = 0;
@@ -292,7 +297,8 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
     }
 }
 
-__global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first) {
+__global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first,
+                                                 uint2 *tok, uint32_t tokcap) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     const int lane = threadIdx.x;
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
     if (!first && plan->pad[1] == 0u) return;                            // no region asked for a re-parse
     for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
         if (!RFL(reg[r].needfull)) continue;
-        rg_parse_region(src, n_src, plan, reg, traces, r, first, s_win, s_tq, lane);
+        rg_parse_region(src, n_src, plan, reg, traces, r, first, s_win, s_tq, lane, tok, tokcap);
         wave_sync();
     }
 }
@@ -601,12 +607,75 @@ __device__ __forceinline__ bool rg_ext(const uint8_t *__restrict__ src, const ui
     }
     return false;
 }
-__global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
-                                                      const uint2 *__restrict__ traces, uint8_t *__restrict__ index, uint32_t *__restrict__ done) {
-    __shared__ uint2 s_tr[RG_BUCKETS + 1];
+// The same entries from the token store (hb_lz4_region.h), when the workspace has one: no walk at all.  One wavefront per region reads the stored
+// tokens 64 at a time; their output lengths add up backwards from the region's end to the output position of the first token on the chain (the
+// one at RgRegion.pad0), forwards to every token's own, and each lane writes the entries of the unit boundaries its sequence holds.  done[r] as
+// k_rg_index_fast leaves it (which then only takes the regions this kernel left at 0: no usable store, a token with 32-bit lengths).
+__global__ __launch_bounds__(64) void k_rg_index_tok(const uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint2 *__restrict__ tok, const uint32_t tokcap,
+                                                     uint8_t *__restrict__ index, uint32_t *__restrict__ done) {
     const int lane = threadIdx.x;
     const uint32_t r = blockIdx.x;
     if (lane == 0) done[r] = 0u;
+    if (!plan->ok || __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || r >= plan->nreg) return;
+    const uint64_t N = plan->total;
+    uint8_t *ents = index + HB_IDX_HDR_BYTES;
+    const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit), outlen = RFL(reg[r].outlen), pad0 = RFL(reg[r].pad0), nt = RFL(reg[r].pad1[0]);
+    if (outlen == 0u || start >= exitp) { if (lane == 0) done[r] = 0xFFFFFFFFu; return; }
+    if (pad0 == RG_INVALID || RFL(reg[r].exit0) != exitp || nt == RG_INVALID || nt == 0u || pad0 >= exitp) return;
+    const uint64_t opos = reg[r].opos;
+    if (opos / HB_CHUNK == (opos + outlen - 1) / HB_CHUNK && (opos & (HB_CHUNK - 1)) != 0) { if (lane == 0) done[r] = 0xFFFFFFFFu; return; }   // no boundary in here
+    const uint2 *tk = tok + (size_t)r * tokcap;
+    // the first stored token on the chain, and what the tokens from there on put out (a token with 32-bit lengths: not here)
+    uint32_t k0 = RG_INVALID;
+    uint64_t tail = 0;
+    bool odd = false;
+    for (uint32_t b = 0; b < nt; b += 64u) {
+        const uint32_t k = b + (uint32_t)lane;
+        uint2 t; t.x = 0; t.y = 0;
+        if (k < nt) t = tk[k];
+        const bool on = k < nt && t.x >= pad0;
+        if (k0 == RG_INVALID) { const unsigned long long m = hb_ballot(on); if (m) k0 = b + (uint32_t)__builtin_ctzll(m); }
+        if (hb_ballot(on && t.y == RG_INVALID)) { odd = true; break; }
+        if (__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // somebody found a boundary inside a match: no index
+        uint32_t o = on ? (t.y & 0xFFFFu) + (t.y >> 16) : 0u;
+        o = wave_incl_scan_dpp(o);
+        tail += (uint32_t)__builtin_amdgcn_readlane(o, 63);
+    }
+    if (odd || k0 == RG_INVALID || tail > outlen) return;
+    if (RFL(tk[k0].x) != pad0) return;                                  // (pad0 is a token of the recorded parse: it is there)
+    uint64_t d = (uint64_t)outlen - tail;                               // output position (from `entry`) of the token at pad0
+    bool inmatch = false;
+    for (uint32_t b = k0; b < nt && !inmatch; b += 64u) {
+        const uint32_t k = b + (uint32_t)lane;
+        uint2 t; t.x = 0; t.y = 0;
+        if (k < nt) t = tk[k];
+        const uint32_t ll = t.y & 0xFFFFu, ml = t.y >> 16;
+        const uint32_t o = k < nt ? ll + ml : 0u;
+        const uint32_t incl = wave_incl_scan_dpp(o);
+        if (k < nt) {
+            const uint64_t g0 = opos + d + (incl - o);                  // absolute output position of my sequence
+            const uint32_t tp = t.x;
+            const uint32_t ls = tp + 1u + (ll >= 15u ? (((ll - 15u) * 0x8081u) >> 23) + 1u : 0u);     // (x / 255 for x < 65536)
+            uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+            if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
+            for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
+            if (U < g0 + ll + ml && U < N) inmatch = true;              // a unit boundary inside a match: the block was not written chunk-locally
+        }
+        inmatch = hb_ballot(inmatch) != 0ull;
+        if (!inmatch && __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        d += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+    }
+    if (inmatch) { if (lane == 0) { done[r] = 6u; if (!__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicExch(&plan->fail, 1u); } return; }
+    if (lane == 0) done[r] = pad0 > start ? pad0 : 0xFFFFFFFFu;        // the head [entry, pad0) is still to do (nothing, when the chain starts on the record)
+}
+
+__global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
+                                                      const uint2 *__restrict__ traces, uint8_t *__restrict__ index, uint32_t *__restrict__ done, int after_tok) {
+    __shared__ uint2 s_tr[RG_BUCKETS + 1];
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    if (after_tok) { if (r < plan->nreg && RFL(done[r]) != 0u) return; }                // k_rg_index_tok did this region (or gave the verdict)
+    else if (lane == 0) done[r] = 0u;
     if (!plan->ok || __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || r >= plan->nreg) return;
     const uint64_t N = plan->total;
     uint8_t *ents = index + HB_IDX_HDR_BYTES;
@@ -798,20 +867,24 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     const size_t ib = hb_lz4_index_bound(a.cap);
     uint64_t rs; uint32_t nreg;
     rg_regions(a.n, &rs, &nreg);
+    // the token store: the first rg_tok_bytes(cap) bytes of the symbolic decoder's scratch, when the caller's workspace has that (hb_lz4_sym.hip)
+    static const bool no_tok = [] { const char *e = getenv("HIPBLOSC_DEBUG_NO_TOKEN_STORE"); return e && *e && *e != '0'; }();   // A/B
+    uint2 *tok = (a.sym_work && !no_tok) ? (uint2 *)a.sym_work : nullptr;
+    const uint32_t tokcap = rg_tokcap(rs);
     HB_HIP_TRY(hipMemsetAsync(idx, 0, ib, s));
     hb_prof_begin("k_rg_parse", s);
     hipLaunchKernelGGL(k_rg_init, dim3((nreg + 255) / 256), dim3(256), 0, s, plan, reg, nreg, (uint32_t)rs);
-    hipLaunchKernelGGL(k_rg_parse, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 1);
+    hipLaunchKernelGGL(k_rg_parse, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 1, tok, tokcap);
     hb_prof_end(s);
     hb_prof_begin("k_rg_fix", s);
     hipLaunchKernelGGL(k_rg_pmax, dim3(1), dim3(1024), 0, s, plan, reg, (uint32_t *)(w + L.pmax));
     hipLaunchKernelGGL(k_rg_fix, dim3((nreg + 63) / 64), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, (const uint32_t *)(w + L.pmax));
-    hipLaunchKernelGGL(k_rg_parse, dim3(nreg < RG_FIXGRID ? nreg : RG_FIXGRID), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
+    hipLaunchKernelGGL(k_rg_parse, dim3(nreg < RG_FIXGRID ? nreg : RG_FIXGRID), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0, tok, tokcap);
     hb_prof_end(s);
     hb_prof_begin("k_rg_settle", s);
     for (int k = 0; k < RG_FIXROUNDS; k++) {                           // (both return at once when an earlier round has settled the chain)
         hipLaunchKernelGGL(k_rg_settle<false>, dim3(1), dim3(1024), 0, s, a.src, (uint64_t)a.n, plan, reg, traces);
-        hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0);
+        hipLaunchKernelGGL(k_rg_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, traces, 0, tok, tokcap);
     }
     hipLaunchKernelGGL(k_rg_settle<true>, dim3(1), dim3(1024), 0, s, a.src, (uint64_t)a.n, plan, reg, traces);
     hipLaunchKernelGGL(k_rg_scan, dim3(1), dim3(1024), 0, s, plan, reg, (uint64_t)a.n, (uint64_t)a.cap);
@@ -819,7 +892,8 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     hb_prof_begin("k_rg_index", s);
     static const bool slow_index = [] { const char *e = getenv("HIPBLOSC_DEBUG_SLOW_INDEX"); return e && *e && *e != '0'; }();   // A/B: the wave-parallel walk only
     uint32_t *done = (uint32_t *)(w + L.pmax);                          // (k_rg_pmax / k_rg_fix are through with it)
-    if (!slow_index) hipLaunchKernelGGL(k_rg_index_fast, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, (const uint2 *)traces, idx, done);
+    if (!slow_index && tok) hipLaunchKernelGGL(k_rg_index_tok, dim3(nreg), dim3(64), 0, s, (uint64_t)a.n, plan, reg, (const uint2 *)tok, tokcap, idx, done);
+    if (!slow_index) hipLaunchKernelGGL(k_rg_index_fast, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, (const uint2 *)traces, idx, done, tok ? 1 : 0);
     hipLaunchKernelGGL(k_rg_index, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, plan, reg, slow_index ? (const uint32_t *)nullptr : (const uint32_t *)done, idx);
     hipLaunchKernelGGL(k_rg_index_head, dim3(1), dim3(1), 0, s, plan, idx, (uint64_t)a.n);
     hb_prof_end(s);

@@ -60,7 +60,7 @@ extern "C" void hb_debug_sy_times(unsigned long long *out, int reset) {
 #define SY_PIECE    (256u << 10)  // bytes of a region one workgroup resolves at a time (k_sy_resolve)
 #define SY_ROUNDS   3             // launches of pass A; the last one copies everything inline
 
-struct SyLayout { size_t plan, par, units, list, big, items, sym, maps, tails, total; };
+struct SyLayout { size_t tok, plan, par, units, list, big, items, sym, maps, tails, total; };
 static inline uint32_t sy_max_groups(size_t n_out) {
     // a group costs 512 KiB of map buffers: at most one per sixteen regions of the longest block n_out bytes can come from (a 1 MiB frame
     // then has 8 groups and 4 MiB of maps, not 256 and 128 MiB)
@@ -71,6 +71,7 @@ static inline SyLayout sy_layout(size_t n_out) {
     SyLayout L; size_t o = 0;
     auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
     const uint32_t g = sy_max_groups(n_out);
+    L.tok = take(rg_tok_bytes(n_out));                           // FIRST: the token discovery's store (hb_lz4_region.h), written by k_rg_parse
     L.plan = take(sizeof(SyPlan));
     L.par = take((size_t)SY_GROUPS * 4 * 2);                  // which of a group's two map buffers is current: two arrays, k_sy_scan flips between them
     L.units = take((size_t)SY_MAXUNITS * sizeof(SyUnit));
