@@ -625,9 +625,10 @@ __global__ __launch_bounds__(64) void k_rg_index_tok(const uint64_t n_src, RgPla
     const uint64_t opos = reg[r].opos;
     if (opos / HB_CHUNK == (opos + outlen - 1) / HB_CHUNK && (opos & (HB_CHUNK - 1)) != 0) { if (lane == 0) done[r] = 0xFFFFFFFFu; return; }   // no boundary in here
     const uint2 *tk = tok + (size_t)r * tokcap;
-    // the first stored token on the chain, and what the tokens from there on put out (a token with 32-bit lengths: not here)
+    // the first stored token on the chain, and what the tokens from there on put out (a token with 32-bit lengths: not here).  Every lane
+    // adds up its own tokens, the sums meet once at the end: no step waits for the one before.
     uint32_t k0 = RG_INVALID;
-    uint64_t tail = 0;
+    uint64_t mysum = 0;
     bool odd = false;
     for (uint32_t b = 0; b < nt; b += 64u) {
         const uint32_t k = b + (uint32_t)lane;
@@ -635,34 +636,43 @@ __global__ __launch_bounds__(64) void k_rg_index_tok(const uint64_t n_src, RgPla
         if (k < nt) t = tk[k];
         const bool on = k < nt && t.x >= pad0;
         if (k0 == RG_INVALID) { const unsigned long long m = hb_ballot(on); if (m) k0 = b + (uint32_t)__builtin_ctzll(m); }
-        if (hb_ballot(on && t.y == RG_INVALID)) { odd = true; break; }
-        if (__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // somebody found a boundary inside a match: no index
-        uint32_t o = on ? (t.y & 0xFFFFu) + (t.y >> 16) : 0u;
-        o = wave_incl_scan_dpp(o);
-        tail += (uint32_t)__builtin_amdgcn_readlane(o, 63);
+        odd = odd || (on && t.y == RG_INVALID);
+        mysum += on ? (t.y & 0xFFFFu) + (t.y >> 16) : 0u;
+        if ((b & 0x3FFu) == 0x3C0u && __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // (every 16th step) no index
     }
-    if (odd || k0 == RG_INVALID || tail > outlen) return;
+    if (hb_ballot(odd) || k0 == RG_INVALID) return;
+    uint64_t tail = mysum;
+    for (int d = 32; d; d >>= 1) tail += (uint64_t)__shfl_xor((unsigned long long)tail, d);
+    if (tail > outlen) return;
     if (RFL(tk[k0].x) != pad0) return;                                  // (pad0 is a token of the recorded parse: it is there)
+    if (__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;         // somebody found a boundary inside a match: no index
     uint64_t d = (uint64_t)outlen - tail;                               // output position (from `entry`) of the token at pad0
     bool inmatch = false;
-    for (uint32_t b = k0; b < nt && !inmatch; b += 64u) {
-        const uint32_t k = b + (uint32_t)lane;
-        uint2 t; t.x = 0; t.y = 0;
-        if (k < nt) t = tk[k];
-        const uint32_t ll = t.y & 0xFFFFu, ml = t.y >> 16;
-        const uint32_t o = k < nt ? ll + ml : 0u;
-        const uint32_t incl = wave_incl_scan_dpp(o);
-        if (k < nt) {
-            const uint64_t g0 = opos + d + (incl - o);                  // absolute output position of my sequence
-            const uint32_t tp = t.x;
-            const uint32_t ls = tp + 1u + (ll >= 15u ? (((ll - 15u) * 0x8081u) >> 23) + 1u : 0u);     // (x / 255 for x < 65536)
-            uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
-            if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
-            for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
-            if (U < g0 + ll + ml && U < N) inmatch = true;              // a unit boundary inside a match: the block was not written chunk-locally
+    // four tokens per lane and step (32 bytes, two 16-byte reads): a quarter of the dependent steps (the running position is the only thing a
+    // step needs from the one before)
+    for (uint32_t b = k0; b < nt && !inmatch; b += 256u) {
+        const uint32_t kb = b + 4u * (uint32_t)lane;
+        uint2 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { t[q].x = 0; t[q].y = 0; if (kb + (uint32_t)q < nt) t[q] = tk[kb + (uint32_t)q]; }
+        uint32_t o[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { o[q] = kb + (uint32_t)q < nt ? (t[q].y & 0xFFFFu) + (t[q].y >> 16) : 0u; tot += o[q]; }
+        const uint32_t incl = wave_incl_scan_dpp(tot);
+        uint64_t g0 = opos + d + (incl - tot);                          // absolute output position of my first sequence
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (kb + (uint32_t)q < nt) {
+                const uint32_t ll = t[q].y & 0xFFFFu, ml = t[q].y >> 16, tp = t[q].x;
+                const uint32_t ls = tp + 1u + (ll >= 15u ? (((ll - 15u) * 0x8081u) >> 23) + 1u : 0u);     // (x / 255 for x < 65536)
+                uint64_t U = (g0 + HB_CHUNK - 1) & ~(uint64_t)(HB_CHUNK - 1);
+                if (U == g0 && U < N) { rg_emit(ents, U, tp, HB_IDX_AT_TOKEN, 0u); U += HB_CHUNK; }
+                for (; U < g0 + ll && U < N; U += HB_CHUNK) rg_emit(ents, U, (uint32_t)(ls + (U - g0)), (uint32_t)(g0 + ll - U), tp);
+                if (U < g0 + ll + ml && U < N) inmatch = true;          // a unit boundary inside a match: the block was not written chunk-locally
+                g0 += o[q];
+            }
         }
         inmatch = hb_ballot(inmatch) != 0ull;
-        if (!inmatch && __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         d += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
     }
     if (inmatch) { if (lane == 0) { done[r] = 6u; if (!__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicExch(&plan->fail, 1u); } return; }
