@@ -163,10 +163,11 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap,
 
 size_t  hb_compress_frame_workspace(size_t n);
 size_t  hb_decompress_frame_workspace(size_t n_out);
-/* the same plus ~2 bytes per output byte: with a workspace of this size an LZ4 / LZ4HC frame that has no restart index and was
+/* the same plus ~5 bytes per output byte: with a workspace of this size an LZ4 / LZ4HC frame that has no restart index and was
  * not written chunk-locally (what the reference's lz4.CompressBlock writes, codec.go:63-75) is decoded in parallel as well
- * (symbolic decode from the verified token chain); with the smaller workspace such a frame goes to one wavefront.  The host-pointer
- * entry points pick the size themselves. */
+ * (symbolic decode from the verified token chain: ~2 bytes per output byte); with the smaller workspace such a frame goes to one
+ * wavefront.  It also holds the token store of the discovery (~2.7 bytes per stream byte), with which the index of a frame of THIS
+ * library that carries none is rebuilt without a second walk (decode ~6 % faster).  The host-pointer entry points pick the size themselves. */
 size_t  hb_decompress_frame_workspace_foreign(size_t n_out);
 int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap,
                           int codec, int level, int shuffle, int typesize, unsigned opts,
@@ -240,7 +241,7 @@ int hb_decompress_frames_batch(int nframes, const void *const *frame, const size
  * A queue belongs to one thread at a time; different queues are independent. */
 typedef struct hb_queue hb_queue;
 hb_queue *hb_queue_create(int device, int depth, size_t max_nbytes);   /* NULL on failure; frames up to max_nbytes uncompressed bytes */
-/* flags: HB_QUEUE_FOREIGN_FRAMES = every slot gets hb_decompress_frame_workspace_foreign(max_nbytes) bytes of workspace (~3x the
+/* flags: HB_QUEUE_FOREIGN_FRAMES = every slot gets hb_decompress_frame_workspace_foreign(max_nbytes) bytes of workspace (~5x the
  * frame size more device memory per slot), so that LZ4 frames of other writers -- no restart index, not chunk-local -- decode in parallel */
 #define HB_QUEUE_FOREIGN_FRAMES 1u
 hb_queue *hb_queue_create_ex(int device, int depth, size_t max_nbytes, unsigned flags);
