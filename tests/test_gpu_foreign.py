@@ -129,6 +129,56 @@ def test_foreign_frames_need_the_larger_workspace(hb, O):
             hip.hipFree(ptr)
 
 
+def test_rebuilt_index_is_the_same_from_stored_tokens_and_from_bucket_records(hb, O):
+    # An own frame without the trailer, decoded through the device-pointer API twice: with the small workspace the index is rebuilt from the
+    # discovery's bucket records (k_rg_index_fast) + the wave walk, with the larger one from the tokens the first parse stored (k_rg_index_tok,
+    # csrc/hb_lz4_region.hip).  Same bytes out, and the SAME index in the workspace (its place: tools/region_debug.py --save-index).
+    L = hb.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    H2D, D2H = 1, 2
+
+    def dmalloc(nb):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), nb) == 0
+        return ptr
+
+    al = lambda v: (v + 255) & ~255
+    for x, shuffle, ts in ((O.synth(O.D_F32, (48 << 20) // 4), 1, 4), (O.synth(O.D_I32, (24 << 20) // 4), 2, 4), (O.synth(O.D_F64, (32 << 20) // 8), 1, 8)):
+        f = np.frombuffer(hb.Compress(x.tobytes(), hb.LZ4, 5, shuffle, ts, opts=0), np.uint8)
+        n = x.nbytes
+        small, large = L.hb_decompress_frame_workspace(n), L.hb_decompress_frame_workspace_foreign(n)
+        bound = n + n // 255 + 16
+        nr_cap = min(max(bound // 8192 + 2, min(bound, 8 << 20) // 4096 + 2), 16384)                 # rg_max_regions (csrc/hb_lz4_region.h)
+        off_idx = al(n) + 256 + 256 + al(64) + al(nr_cap * 64) + al(nr_cap * 4) + al(nr_cap * 256 * 8)
+        nun = (n + 4095) // 4096
+        idx_bytes = 32 + 16 * (nun + 1)
+        d_frame, d_out, d_res, d_work = dmalloc(f.size + 64), dmalloc(n), dmalloc(64), dmalloc(large)
+        try:
+            assert hip.hipMemcpy(d_frame, f.ctypes.data, f.size, H2D) == 0
+            got = []
+            for wb in (small, large):
+                assert hip.hipMemset(d_out, 0, n) == 0 and hip.hipMemset(d_work, 0, off_idx + idx_bytes) == 0
+                rc = L.hb_decompress_frame_dev(d_frame, f.size, d_out, n, 0, d_work, wb, d_res, None)
+                assert rc == 0 and hip.hipDeviceSynchronize() == 0
+                res = np.zeros(32, np.uint8)
+                back = np.empty(n, np.uint8)
+                index = np.empty(idx_bytes, np.uint8)
+                assert hip.hipMemcpy(res.ctypes.data, d_res, 32, D2H) == 0 and hip.hipMemcpy(back.ctypes.data, d_out, n, D2H) == 0
+                assert hip.hipMemcpy(index.ctypes.data, ctypes.c_void_p(d_work.value + off_idx), idx_bytes, D2H) == 0
+                assert int(res[:4].view(np.int32)[0]) == 0 and int(res[4:8].view(np.uint32)[0]) & 1 == 1
+                assert np.array_equal(back, x.view(np.uint8).reshape(-1))
+                assert index[:4].tobytes() == b"HBIX" or int(index[:4].view(np.uint32)[0]) != 0
+                got.append(index)
+            assert np.array_equal(got[0], got[1]), (shuffle, ts)
+        finally:
+            for ptr in (d_frame, d_out, d_res, d_work):
+                hip.hipFree(ptr)
+
+
 def test_own_frames_without_the_trailer_decode_in_parallel(hb, O):
     # what Compress() returns by default (opts = 0): the index is rebuilt on the device and checked like a stored one
     for name, (x, shuffle, ts, _) in _cases(O).items():
