@@ -255,3 +255,72 @@ __device__ __forceinline__ bool rg_walk(const uint8_t *__restrict__ src, const u
     }
     return drain(true);
 }
+
+// ---- the walk fed from the token store (rg_tokcap above): the tokens tk[k0 .. k1) of ONE region, all on the verified chain.  Nothing is parsed:
+// the stream window is staged for the literals and the offsets, 64 stored tokens are read per step (the next 64 while this batch is decoded) and
+// handed to `batch` as rg_walk hands them over.  At a token that does not fit the window, carries 32-bit lengths or is the block's literal-only end
+// it stops and says so (k0 = that token: the caller has rg_walk parse exactly that one and comes back).  Returns 0: a callback stopped the walk,
+// 1: through, 2: stopped at token k0.  Used by pass A of the symbolic decoder where nearly every region is token-dense (k_sy_gate).
+struct RgTokStore { const RgRegion *reg; const uint2 *tok; uint32_t tokcap, rs, nreg; };
+// first index in tk[0 .. nt) whose position is >= pos (positions ascend); wave-uniform
+__device__ __forceinline__ uint32_t rg_tok_lower(const uint2 *__restrict__ tk, const uint32_t nt, const uint32_t pos, const int lane) {
+    uint32_t lo = 0, hi = nt;                                           // the answer is in [lo, hi]
+    while (hi - lo > 64u) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t k = lo + (uint32_t)lane * step;
+        const bool ge = k >= hi || tk[k].x >= pos;
+        const unsigned long long m = hb_ballot(ge);
+        const uint32_t j = m ? (uint32_t)__builtin_ctzll(m) : 64u;      // first probe that is not below pos (lane 0 probes lo)
+        if (j == 0u) return lo;
+        const uint32_t nhi = lo + j * step < hi ? lo + j * step : hi;
+        lo = lo + (j - 1u) * step;
+        hi = nhi;
+    }
+    const uint32_t k = lo + (uint32_t)lane;
+    const unsigned long long m = hb_ballot(k >= hi || tk[k].x >= pos);
+    return m ? lo + (uint32_t)__builtin_ctzll(m) : hi;
+}
+template <uint32_t PWIN = RG_PWIN, class Batch>
+__device__ __forceinline__ int rg_walk_tok(const uint8_t *__restrict__ src, const uint64_t n_src, const uint2 *__restrict__ tk, uint32_t &k0, const uint32_t k1,
+                                           uint8_t *s_win /* PWIN + 128 */, const int lane, Batch &&batch) {
+    uint64_t wpos = 0;
+    uint32_t wlen = 0, wsh = 0;
+    wave_sync();
+    uint2 nx; nx.x = 0; nx.y = 0;
+    uint32_t nxk = RG_INVALID;                                          // nx holds tk[nxk + lane]
+    while (k0 < k1) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        uint2 t; t.x = 0; t.y = 0;
+        const bool have = k < k1;
+        if (nxk == k0) t = nx; else if (have) t = tk[k];
+        nxk = k0 + 64u;
+        nx.x = 0; nx.y = 0;
+        if (nxk + (uint32_t)lane < k1) nx = tk[nxk + (uint32_t)lane];
+        const uint32_t tp = t.x, lit = t.y & 0xFFFFu, mlen = t.y >> 16;
+        const uint32_t ls = tp + 1u + (lit >= 15u ? (((lit - 15u) * 0x8081u) >> 23) + 1u : 0u);     // (x / 255 for x < 65536)
+        const uint32_t tp0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tp);
+        if (tp0 < wpos || tp0 - wpos + PWIN / 4u > wlen) {              // move the window (as rg_walk does: once less than a quarter is left)
+            const uint8_t *g = src + tp0;
+            wsh = (uint32_t)((uintptr_t)g & 15u);
+            const uint64_t left = n_src - tp0;
+            wlen = (uint32_t)(left < (uint64_t)(PWIN - 16u) ? left : (uint64_t)(PWIN - 16u));
+            const u32x4 *ga = (const u32x4 *)(g - wsh);
+            const uint32_t nv = (wsh + wlen + 15u) >> 4;
+            wave_sync();
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+            wpos = tp0;
+            wave_sync();
+        }
+        // leading tokens that lie in the window whole (token, literals, offset) and are ordinary
+        const bool fits = have && t.y != RG_INVALID && mlen != 0u && (uint64_t)ls + lit + 2u <= wpos + wlen;
+        const unsigned long long nm = hb_ballot(!fits);
+        const uint32_t cnt = nm ? (uint32_t)__builtin_ctzll(nm) : 64u;
+        if (cnt == 0u) return 2;                                        // this token the slow way (any size; the block's final sequence)
+        const uint32_t lw = (uint32_t)(ls - wpos);                      // first literal, window-relative
+        uint32_t off = 0;
+        if ((uint32_t)lane < cnt) off = (uint32_t)s_win[wsh + lw + lit] | ((uint32_t)s_win[wsh + lw + lit + 1u] << 8);
+        if (!batch(cnt, tp, ls, lit, mlen, off, wsh + lw)) return 0;
+        k0 += cnt;
+    }
+    return 1;
+}

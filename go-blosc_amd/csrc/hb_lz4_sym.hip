@@ -102,7 +102,8 @@ static uint32_t hb_sy_slots() {
 // share a unit only while that leaves at least 3/4 of the slots with a unit each (the headline frame as the reference writes it: 6876 regions -> 4025
 // units on 4352 slots; random floats have 2860 token-dense regions behind three incompressible planes: merged into 879 units they kept a fifth
 // of the chip busy for 5.3 ms, unmerged 2.0 ms).
-__global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegion *__restrict__ reg, const DecPlan *dp, SyPlan *sy, uint32_t groups, uint32_t per, uint32_t slots) {
+__global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegion *__restrict__ reg, const DecPlan *dp, SyPlan *sy, uint32_t groups, uint32_t per, uint32_t slots,
+                                                  int have_tok) {
     __shared__ uint32_t s_n[16];
     const int t = threadIdx.x;
     const uint32_t go = (rg->ok && !(dp->mode == DEC_INDEXED && !dp->fail)) ? 1u : 0u;
@@ -119,6 +120,12 @@ __global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegi
         // merge level: groups of 2^merge neighbours share a unit; pairs while live / 2 >= 3/4 slots.  (Groups of four when that still fills the
         // slots -- bit-shuffled data, 16378 token-dense regions -- were measured: k_sy_compose 1.35 -> 0.98 ms, but pass A 6.2 -> 9.2: one
         // generation of long units ends with its slowest one, two generations of shorter ones are dealt out as slots come free.)
+        // pass A from the discovery's token store (k_sy_decode<true>): where nearly every region holds tokens (3 of 4: bit-shuffled data as the
+        // reference writes it: +15 %); a frame with incompressible planes leaves it less to gain than the longer kernel costs (headline frame: -3.5 %)
+#ifndef SY_TOK_NUM
+#define SY_TOK_NUM 3u                                                   // of 4 regions
+#endif
+        sy->usetok = (have_tok && (uint64_t)live * 4u >= (uint64_t)rg->nreg * SY_TOK_NUM) ? 1u : 0u;
         sy->live = live; sy->merge = (uint64_t)live * 2u >= (uint64_t)slots * 3u ? 1u : 0u;
     }
 }
@@ -229,15 +236,18 @@ __global__ __launch_bounds__(1024) void k_sy_compact(SyPlan *sy, const SyUnit *_
 // and is resumed by the next launch, after k_sy_big has done all posted copies with the whole chip.  The LAST launch copies inline.
 // Unit state between launches (SyUnit): rtp = stream position of the token to resume at, rout = output position there, state bit 0 = unit
 // done, bit 1 = the literal run of the token at rtp was posted (the rest of that sequence is on record and is not parsed again).
+template <bool TOK>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SY_WAVES))) void k_sy_decode(const uint8_t *__restrict__ src, uint64_t n_src, SyUnit *un, const uint32_t *__restrict__ list,
-                                                   SyPlan *sy, SyBig *big, uint8_t *D, uint16_t *S, int last) {
+                                                   SyPlan *sy, SyBig *big, uint8_t *D, uint16_t *S, int last, const RgPlan *rg, const RgRegion *reg,
+                                                   const uint2 *tok, uint32_t tokcap) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[SY_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     __shared__ __attribute__((aligned(16))) uint8_t s_d[SY_IMG + 64];
     __shared__ __attribute__((aligned(16))) uint16_t s_s[SY_IMG + 64];
-    if (!sy->go || sy->fail) return;
+    if (!sy->go || sy->fail || (sy->usetok != 0u) != TOK) return;      // (both kernels are launched; k_sy_gate picked one)
     const int lane = threadIdx.x;
     const uint32_t nact = sy->nact;
+    RgTokStore ts; ts.reg = reg; ts.tok = tok; ts.tokcap = tokcap; ts.rs = TOK ? rg->rs : 1u; ts.nreg = TOK ? rg->nreg : 0u;
     for (uint32_t i = blockIdx.x; i < nact; i += gridDim.x) {
         SyUnit *R = un + list[i];
         const uint32_t entry = RFL(R->entry), exitp = RFL(R->exit);
@@ -250,7 +260,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SY_WAVES))) 
         const uint32_t start = cont ? rtp : entry;
         uint32_t out = cont ? RFL(R->rout) : O;        // next output byte
         bool parked;
-        const bool ok = sy_decode_unit<true, SY_PWIN>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen));
+        const bool ok = sy_decode_unit<true, SY_PWIN, TOK>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen),
+                                                           TOK ? &ts : nullptr);
         if (!parked) {
             if ((!ok || out != O + RFL(R->outlen)) && lane == 0) atomicExch(&sy->fail, 1u);
             if (lane == 0) R->state = 1u;
@@ -571,14 +582,19 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     SyBig *big = (SyBig *)(sym_work + L.big);
     uint32_t *list = (uint32_t *)(sym_work + L.list);
     hb_prof_begin("k_sy_units", s);
-    hipLaunchKernelGGL(k_sy_gate, dim3(1), dim3(1024), 0, s, rg, (const RgRegion *)reg, dp, sy, groups, per, hb_sy_slots());
+    static const bool no_tok = [] { const char *e = getenv("HIPBLOSC_DEBUG_NO_TOKEN_STORE"); return e && *e && *e != '0'; }();   // A/B (k_rg_parse then wrote none either)
+    const uint2 *tok = no_tok ? nullptr : (const uint2 *)(sym_work + L.tok);
+    hipLaunchKernelGGL(k_sy_gate, dim3(1), dim3(1024), 0, s, rg, (const RgRegion *)reg, dp, sy, groups, per, hb_sy_slots(), tok ? 1 : 0);
     hipLaunchKernelGGL(k_sy_units, dim3((nreg + 3) / 4), dim3(64), 0, s, rg, reg, (const uint2 *)(w + RL.trace), sy, un);
     hipLaunchKernelGGL(k_sy_compact, dim3(1), dim3(1024), 0, s, sy, un, list);
     hb_prof_end(s);
     for (int k = 0; k < SY_ROUNDS; k++) {
         const int last = k + 1 == SY_ROUNDS;
         hb_prof_begin("k_sy_decode", s);
-        hipLaunchKernelGGL(k_sy_decode, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last);
+        hipLaunchKernelGGL(k_sy_decode<false>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
+                           (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));
+        if (tok) hipLaunchKernelGGL(k_sy_decode<true>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
+                                    (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));
         hb_prof_end(s);
         if (!last) {
             hb_prof_begin("k_sy_big", s);

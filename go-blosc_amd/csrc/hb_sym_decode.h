@@ -13,7 +13,7 @@
 #define SY_BIG      (256u << 10)  // literal runs / matches from this size on are copied by the whole chip (k_sy_big)
 #endif
 
-struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact, live, merge; uint32_t pad[7]; };   // per: units WITH OUTPUT per group of pass B; live: regions with output; merge: light neighbours share a unit
+struct SyPlan { uint32_t go, fail, groups, per, nbig, nunits, nact, live, merge, usetok; uint32_t pad[6]; };   // per: units WITH OUTPUT per group of pass B; live: regions with output; merge: light neighbours share a unit
 // what one wavefront of pass A decodes: a region of the token discovery, or one of SY_SUB parts of a region whose output is large
 // state: bit 0 done, bit 1: the literal run of the token at rtp is being / has been copied by k_sy_big -- the rest of that sequence is on record
 // (plit / pmlen / poff, pnext = the token behind it): a resumed unit never parses a parked token again (the length extension of a 256 MiB run is a
@@ -261,11 +261,12 @@ __device__ __forceinline__ void sy_match_wave(uint8_t *D, uint16_t *S, const uin
 // R / sy / big: where a unit of the symbolic decoder parks in front of a big copy (NULL: never parks).  Returns false when the
 // stream is not what the chain promised (offset 0, offset in front of `base`, a final sequence that announces a match, output past
 // `limit`: nothing is written there).
-template <bool SYM, uint32_t PWIN = RG_PWIN>
+// TOK: the stretch is walked region by region of the token discovery and fed from its token store `ts` where that is usable (see below).
+template <bool SYM, uint32_t PWIN = RG_PWIN, bool TOK = false>
 __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, const uint64_t n_src, const uint32_t start, const uint32_t exitp, const uint32_t base,
                                                const uint32_t O, uint32_t &out, uint8_t *D, uint16_t *S, uint8_t *s_win, uint2 *s_tq, uint8_t *s_d, uint16_t *s_s,
                                                const int lane, const int last, const uint32_t rtp, const uint32_t st, SyUnit *R, SyPlan *sy, SyBig *big, bool &parked,
-                                               const uint32_t limit) {
+                                               const uint32_t limit, const RgTokStore *ts = nullptr) {
         uint8_t *Sb = (uint8_t *)S;
         parked = false;
         const bool resumed = SYM && R != nullptr && (st & 2u) != 0u;             // behind a literal run k_sy_big copied (see SyUnit)
@@ -495,7 +496,51 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             walk_from = RFL(R->pnext);
             ok = single(rtp, ls, lit, mlen, off, mlen ? 0u : (uint32_t)src[rtp] & 0xF0u);
         }
-        if (ok && !parked) ok = rg_walk<PWIN>(src, n_src, walk_from, exitp, s_win, s_tq, lane, batch, single);
+        if constexpr (!TOK) {
+            if (ok && !parked) ok = rg_walk<PWIN>(src, n_src, walk_from, exitp, s_win, s_tq, lane, batch, single);
+        } else {
+            // Region by region of the token discovery: where a region's first parse left its tokens (from RgRegion.pad0 on they are the chain's, if that
+            // parse ends where the chain does), they are read, not parsed again (rg_walk_tok); the stretch in front of pad0 -- what the first parse
+            // needed to fall onto the chain -- regions without a usable store and tokens the store cannot hand over are parsed as before.  One call site
+            // per walker: every inlined copy carries the whole batch decoder.  (Round 3: +15 % on frames that are token-dense everywhere -- bit-shuffled
+            // data as the reference writes it -- and -3.5 % on the headline frame, whose incompressible plane leaves this kernel less to gain than the
+            // longer code costs: k_sy_gate picks the kernel.)
+            uint32_t pos = walk_from;
+            const uint2 *tk = nullptr;
+            uint32_t k0 = 0, k1 = 0, tokend = 0;                            // stored tokens still to read: tk[k0 .. k1), then the position is tokend
+            while (ok && !parked && (pos < exitp || k0 < k1)) {
+                uint32_t wfrom = pos, seg_end = exitp;                      // walk [wfrom, seg_end) unless the store takes over
+                bool one = false;                                           // walking ONE token the store could not hand over
+                if (k0 < k1) {
+                    const int rc = rg_walk_tok<PWIN>(src, n_src, tk, k0, k1, s_win, lane, batch);
+                    if (rc == 0) { ok = false; break; }
+                    if (rc == 1) { pos = tokend; k0 = k1 = 0; continue; }
+                    wfrom = RFL(tk[k0].x); seg_end = wfrom + 1u; one = true; k0 += 1u;   // rg_walk parses exactly that token
+                } else if (ts != nullptr) {
+                    const uint32_t r = pos / ts->rs;
+                    if (r < ts->nreg) {
+                        const RgRegion *G = ts->reg + r;
+                        const uint32_t gexit = RFL(G->exit), pad0 = RFL(G->pad0), nt = RFL(G->pad1[0]);
+                        const uint32_t rend = gexit < exitp ? gexit : exitp;             // where this unit's share of region r ends
+                        if (rend > pos) {
+                            seg_end = rend;
+                            const bool usable = nt != RG_INVALID && nt != 0u && pad0 != RG_INVALID && RFL(G->exit0) == gexit && pad0 < rend;
+                            if (usable && pos < pad0) seg_end = pad0;                    // the head first
+                            else if (usable) {
+                                tk = ts->tok + (size_t)r * ts->tokcap;
+                                k0 = rg_tok_lower(tk, nt, pos, lane);
+                                k1 = rend >= gexit ? nt : rg_tok_lower(tk, nt, rend, lane);
+                                if (k0 < k1 && RFL(tk[k0].x) == pos) { tokend = rend; continue; }
+                                k0 = k1 = 0;                                             // (pos is not a stored token: walk)
+                            }
+                        }
+                    }
+                }
+                ok = rg_walk<PWIN>(src, n_src, wfrom, seg_end, s_win, s_tq, lane, batch, single);
+                if (!one) pos = seg_end;
+                else if (k0 >= k1) { pos = tokend; k0 = k1 = 0; }
+            }
+        }
         if (!parked) flush();
 #ifdef SY_DEBUG_TIMES
         dbg_t[0] = SYT_NOW() - dbg_t0;
