@@ -120,12 +120,10 @@ __global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegi
         // merge level: groups of 2^merge neighbours share a unit; pairs while live / 2 >= 3/4 slots.  (Groups of four when that still fills the
         // slots -- bit-shuffled data, 16378 token-dense regions -- were measured: k_sy_compose 1.35 -> 0.98 ms, but pass A 6.2 -> 9.2: one
         // generation of long units ends with its slowest one, two generations of shorter ones are dealt out as slots come free.)
-        // pass A from the discovery's token store (k_sy_decode<true>): where nearly every region holds tokens (3 of 4: bit-shuffled data as the
-        // reference writes it: +15 %); a frame with incompressible planes leaves it less to gain than the longer kernel costs (headline frame: -3.5 %)
-#ifndef SY_TOK_NUM
-#define SY_TOK_NUM 3u                                                   // of 4 regions
-#endif
-        sy->usetok = (have_tok && (uint64_t)live * 4u >= (uint64_t)rg->nreg * SY_TOK_NUM) ? 1u : 0u;
+        // pass A from the discovery's token store (k_sy_decode<true>) whenever there is one.  (As ONE kernel with a run-time switch the longer code
+        // spilled 57 registers and lost 3.5 % on the headline frame; as a kernel of its own -- 11 spills -- it wins everywhere: the headline
+        // reference frame 2.95 -> 2.30 ms, bit-shuffled ones 6.2 -> 4.65, random floats 2.94 -> 2.11.)
+        sy->usetok = have_tok ? 1u : 0u;
         sy->live = live; sy->merge = (uint64_t)live * 2u >= (uint64_t)slots * 3u ? 1u : 0u;
     }
 }
@@ -591,10 +589,10 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     for (int k = 0; k < SY_ROUNDS; k++) {
         const int last = k + 1 == SY_ROUNDS;
         hb_prof_begin("k_sy_decode", s);
-        hipLaunchKernelGGL(k_sy_decode<false>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
-                           (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));
         if (tok) hipLaunchKernelGGL(k_sy_decode<true>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
                                     (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));
+        else hipLaunchKernelGGL(k_sy_decode<false>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
+                                (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));      // (HIPBLOSC_DEBUG_NO_TOKEN_STORE: A/B)
         hb_prof_end(s);
         if (!last) {
             hb_prof_begin("k_sy_big", s);

@@ -502,9 +502,9 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             // Region by region of the token discovery: where a region's first parse left its tokens (from RgRegion.pad0 on they are the chain's, if that
             // parse ends where the chain does), they are read, not parsed again (rg_walk_tok); the stretch in front of pad0 -- what the first parse
             // needed to fall onto the chain -- regions without a usable store and tokens the store cannot hand over are parsed as before.  One call site
-            // per walker: every inlined copy carries the whole batch decoder.  (Round 3: +15 % on frames that are token-dense everywhere -- bit-shuffled
-            // data as the reference writes it -- and -3.5 % on the headline frame, whose incompressible plane leaves this kernel less to gain than the
-            // longer code costs: k_sy_gate picks the kernel.)
+            // per walker: every inlined copy carries the whole batch decoder.  (Round 3: pass A 2.95 -> 2.30 ms on the headline reference frame, 6.2 -> 4.65
+            // on bit-shuffled data -- as a kernel of its own; sharing one kernel with the parsing walk behind a run-time switch it spilled 57 registers
+            // and lost.)
             uint32_t pos = walk_from;
             const uint2 *tk = nullptr;
             uint32_t k0 = 0, k1 = 0, tokend = 0;                            // stored tokens still to read: tk[k0 .. k1), then the position is tokend
