@@ -306,8 +306,15 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
     if (!first && plan->pad[1] == 0u) return;                            // no region asked for a re-parse
     for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
         if (!RFL(reg[r].needfull)) continue;
+#ifdef RG_DEBUG_TIMES
+        const uint64_t t0 = wall_clock64();
+        const uint32_t had0 = RFL(reg[r].exit0);
+#endif
         rg_parse_region(src, n_src, plan, reg, traces, r, first, s_win, s_tq, lane, tok, tokcap);
         wave_sync();
+#ifdef RG_DEBUG_TIMES
+        if (!first && lane == 0) { reg[r].pad1[3] += (uint32_t)((wall_clock64() - t0) / 100); reg[r].pad1[2] = had0 == RG_INVALID ? 2u : 1u; }     // microseconds; re-parse kind
+#endif
     }
 }
 

@@ -83,6 +83,12 @@ def main():
         lo, hi = (int(v) for v in a.dump.split(":"))
         for i in range(lo, min(hi, nreg)):
             print(f"  r{i}: b {b[i]} entry {entry[i]} exit {exit_[i]} outlen {outlen[i]} | entry0 {entry0[i]} exit0 {exit0[i]} outlen0 {outlen0[i]} ntrace {ntrace[i]} needfull {needfull[i]} pad0 {regs[i, 9]}")
+    rep_us = regs[:, 15]
+    if rep_us.any():                                 # a -DRG_DEBUG_TIMES build: microseconds every region spent in re-parses (k_rg_parse behind the first), kind 2 = full
+        order = np.argsort(-rep_us.astype(np.int64))[:8]
+        print("re-parsed regions", int((rep_us != 0).sum()), "total us", int(rep_us.sum()), "full re-parses", int((regs[:, 14] == 2).sum()))
+        for i in order:
+            print(f"  r{i}: {rep_us[i]} us kind {regs[i, 14]} | b {b[i]} entry {entry[i]} exit {exit_[i]} outlen {outlen[i]} entry0 {entry0[i]} exit0 {exit0[i]} ntrace {ntrace[i]} pad0 {regs[i, 9]}")
     # k_rg_index_fast's verdict per region (round 3): the done[] words live where k_rg_pmax's scratch was (RgLayout.pmax)
     al = lambda v: (v + 255) & ~255
     bound = n + n // 255 + 16
