@@ -51,7 +51,9 @@ extern "C" void hb_debug_sy_times(unsigned long long *out, int reset) {
 #endif
 
 #define SY_W        65536u        // entries of a tail map / bytes of a tail image (index = distance 1..65535; entry 0 unused)
+#ifndef SY_GROUPS
 #define SY_GROUPS   256u          // groups of units in pass B (128: k_sy_compose 1.9 ms, 256: 1.05, 512: 1.0 but the scan over the groups 0.4)
+#endif
 #define SY_SUB      8u            // a region with more than SY_HEAVY bytes of output is decoded in this many parts
 #ifndef SY_HEAVY
 #define SY_HEAVY    (256u << 10)  // (1 MiB until regions went down to 8 KiB: a short frame's 100:1 plane then sat in a few 800 KiB units -- 4 MiB frame 2.9 -> 1.8 ms)
