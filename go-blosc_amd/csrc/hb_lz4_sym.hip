@@ -429,6 +429,10 @@ __device__ __forceinline__ void sy_resolve_range(uint8_t *D, const uint16_t *__r
     if (a1 + t < p1) { const uint32_t p = a1 + t, s = S[p]; if (s) D[p] = s_ring[(O - s) & 0xFFFFu]; }
     for (uint32_t p = a0 + (uint32_t)t * 16u; p < a1; p += (uint32_t)NT * 16u) {
         const u32x4 sa = ld16u((const uint8_t *)(S + p)), sb = ld16u((const uint8_t *)(S + p + 8));
+#ifdef SY_DEBUG_TIMES
+        atomicAdd(&sy_dbg[40], 1ull);                                   // 16-byte groups looked at / with references: how sparse the references are
+        if ((sa.x | sa.y | sa.z | sa.w | sb.x | sb.y | sb.z | sb.w) != 0u) atomicAdd(&sy_dbg[41], 1ull);
+#endif
         if ((sa.x | sa.y | sa.z | sa.w | sb.x | sb.y | sb.z | sb.w) == 0u) continue;
         u32x4 v = ld16u(D + p);
         const uint32_t ss[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
