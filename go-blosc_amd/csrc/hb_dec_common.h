@@ -126,21 +126,42 @@ __device__ __forceinline__ void dec_match_copy(uint8_t *s_out, uint32_t md, uint
 // DRAIN: one queued token per lane, while 64 are queued (or `stop` and any are).  out[0] is the first byte of the image,
 // `hist` bytes before it are valid match sources, `outlen` is the room.  A token that does not fit is not decoded:
 // `rewound` is set and si goes back to that token.  Returns false on a match that reaches before out[-hist] or has offset 0.
+// LEAN (the indexed LZ4 decoder, round 4): the queue holds only the POSITIONS of the tokens (u16, slice-relative; dec_fill_lean) and the
+// fields are parsed here, by 64 lanes that all hold a real token -- the window parser then spends its instructions on finding the chain,
+// not on parsing 64 "as if" tokens of which a dozen are real.  A token whose length extension is longer than one byte is not decoded:
+// like a sequence that passes the end of the unit it rewinds to the one-sequence-at-a-time path.
+template <bool LEAN = false>
 __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, uint8_t *s_out, const uint32_t outlen, const uint32_t hist,
                                           uint32_t &di, uint32_t &si, uint32_t &nq, uint2 *s_tq, const bool stop,
                                           bool &rewound, const int lane) {
     bool ok = true;
     while (nq >= 64u || (stop && nq > 0u)) {
         const uint32_t cntb = nq < 64u ? nq : 64u;
-        const uint2 e = s_tq[lane];
-        const uint32_t lsrc = (uint32_t)((int)(e.x & 0x1FFFu) + inoff), lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22;
-        const uint32_t offv = e.y & 0xFFFFu, tp = e.y >> 16;
+        uint32_t lsrc, lit, mlen, offv, tp;
+        unsigned long long xm = 0;                       // LEAN: tokens this path does not decode (multi-byte length extensions)
+        if constexpr (LEAN) {
+            tp = ((const uint16_t *)s_tq)[lane];
+            const uint32_t w = dec_read4(in, (uint32_t)((int)tp + inoff));
+            const uint32_t t = w & 255u, b1 = (w >> 8) & 255u;
+            const bool big = t >= 0xF0u;
+            lit = big ? 15u + b1 : (t >> 4);
+            lsrc = (uint32_t)((int)tp + inoff) + (big ? 2u : 1u);
+            const uint32_t x = dec_read4(in, lsrc + lit);
+            offv = x & 0xFFFFu;
+            const uint32_t mb = (x >> 16) & 255u, mn = t & 15u;
+            mlen = mn == 15u ? 19u + mb : 4u + mn;
+            xm = hb_ballot((big && b1 == 255u) || (mn == 15u && mb == 255u));
+        } else {
+            const uint2 e = s_tq[lane];
+            lsrc = (uint32_t)((int)(e.x & 0x1FFFu) + inoff); lit = (e.x >> 13) & 0x1FFu; mlen = e.x >> 22;
+            offv = e.y & 0xFFFFu; tp = e.y >> 16;
+        }
         const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
         const uint32_t incl = dec_incl_scan(olen, lane);
         const uint32_t dpos = di + incl - olen;
         uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         unsigned long long amask = cntb >= 64u ? ~0ull : ((1ull << cntb) - 1ull);
-        const unsigned long long om = hb_ballot(olen != 0u && dpos + olen > outlen);
+        const unsigned long long om = (hb_ballot(olen != 0u && dpos + olen > outlen) | xm) & amask;
         if (om) {                                        // this sequence passes the end of the unit: slow path from its token
             const int jx = __builtin_ctzll(om);
             amask &= (1ull << jx) - 1ull;
@@ -153,8 +174,13 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
         // (a token with mlen == 0 carries no match: the Snappy decoder queues literal elements that way)
         if (hb_ballot(istok && mlen != 0u && (offv == 0u || offv > dpos + lit + hist))) { ok = false; break; }
         // literals: short runs by their own lane, long runs by the whole wave
+#if !(defined(LAB_DEC) && (LAB_DEC & 1))     /* lab ablation bit 0: no literal copies (garbage output, timing only) */
         if (istok && lit <= DLITCAP) lds_copy_exact(s_out + dpos, in + lsrc, lit);
+#endif
         unsigned long long lm = hb_ballot(istok && lit > DLITCAP);
+#if defined(LAB_DEC) && (LAB_DEC & 1)
+        lm = 0;
+#endif
         while (lm) {
             const int l = __builtin_ctzll(lm);
             const uint32_t sp = __builtin_amdgcn_readlane(lsrc, l), dp = __builtin_amdgcn_readlane(dpos, l);
@@ -170,6 +196,9 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
         const int srcend = src0 + (int)(mlen < offv ? mlen : offv);        // end of the source that is not my own output
         const uint32_t mend = mdv + mlen;                              // end of my match
         unsigned long long pend = amask & hb_ballot(mlen != 0u);
+#if defined(LAB_DEC) && (LAB_DEC & 2)        /* lab ablation bit 1: no match copies */
+        pend = 0;
+#endif
         while (pend) {
             const int f = __builtin_ctzll(pend);
             const uint32_t X = __builtin_amdgcn_readlane(mdv, f);
@@ -192,9 +221,15 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
         }
         di += total;
         if (rewound) { nq = 0; break; }
-        const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];   // keep what is queued beyond the 64 just decoded
-        nq -= cntb;
-        if ((uint32_t)lane < nq) s_tq[lane] = rest;
+        if constexpr (LEAN) {
+            const uint16_t rest = ((const uint16_t *)s_tq)[64 + lane];  // keep what is queued beyond the 64 just decoded
+            nq -= cntb;
+            if ((uint32_t)lane < nq) ((uint16_t *)s_tq)[lane] = rest;
+        } else {
+            const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
+            nq -= cntb;
+            if ((uint32_t)lane < nq) s_tq[lane] = rest;
+        }
     }
     return ok;
 }
@@ -302,6 +337,52 @@ __device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh,
             uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
             s_tq[nq + rank] = e;
         }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+    }
+    return stop;
+}
+
+// FILL, lean: like dec_fill, but a lane only works out how LONG the sequence would be that starts at its byte (token, at most one
+// extension byte per length, literals, offset: two byte reads and a handful of VALU), the chain is followed as before, and the queue gets
+// the positions of the real tokens (u16); dec_drain<true> parses the fields of the 64 tokens it decodes.  An extension byte is taken to
+// be the only one here; dec_drain<true> looks at it and rewinds at a token where that does not hold.
+__device__ __forceinline__ bool dec_fill_lean(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, const uint32_t slen,
+                                              uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si == slen) { stop = true; break; }
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t t = s_in[sh + p], b1 = s_in[sh + p + 1u];
+        const uint32_t lit = t >= 0xF0u ? 16u + b1 : (t >> 4);                     // literals (+ their extension byte)
+        const uint32_t len = lit + ((t & 15u) == 15u ? 4u : 3u);                    // token + literals + offset (+ the match extension byte)
+        const uint32_t nrel = (uint32_t)lane + len;
+        // a token whose fields do not lie inside the staged bytes (with room for the dword reads of the drain) ends the walk
+        const unsigned long long cmask = hb_ballot(p + len + 1u > lim);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const unsigned long long selfm = cmask | hb_ballot(nrel >= 64u);
+            const uint32_t succ = ((selfm >> lane) & 1ull) ? (uint32_t)lane : nrel;   // the last token of the window points at itself
+            uint32_t j = 0, lastj;
+            for (;;) {                                       // unrolled by 4: setting the last bit again is harmless
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            const unsigned long long cm = tmask & cmask;  // at most the last visited lane
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) ((uint16_t *)s_tq)[nq + rank] = (uint16_t)p;
         nq += (uint32_t)__builtin_popcountll(tmask);
         si = cur;
     }

@@ -72,6 +72,9 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
 #endif
 #define DEC_IN_MARGIN 320u               // a token closer than this to the end of the window is parsed after re-staging
 #define DEC_OUT_MAX HB_CHUNK             // largest output a unit may have
+#ifndef DEC_LEAN
+#define DEC_LEAN 1                       // the window parser only finds the token chain; the drain parses the tokens it decodes (hb_dec_common.h)
+#endif
 #ifndef DEC_WAVES
 #define DEC_WAVES 5
 #endif
@@ -87,6 +90,14 @@ struct DecCtx {
     uint32_t nbytes, nunits;
     int bun4, ush;
 };
+// lab ablations of the fused un-shuffle flush (tools/lab/ab.py; the frames decode to garbage under 1 / 2: timing only)
+#if defined(LAB_DEC_FLUSH) && LAB_DEC_FLUSH == 1
+#define LAB_FLUSH_USH() do { } while (0)
+#elif defined(LAB_DEC_FLUSH) && LAB_DEC_FLUSH == 2
+#define LAB_FLUSH_USH() do { for (uint32_t i = lane * 16u; i < outlen; i += 1024u) st16u(dst + d0 + i, *(const u32x4 *)(s_out + i)); } while (0)
+#else
+#define LAB_FLUSH_USH() do { for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i]; } while (0)
+#endif
 __device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint8_t *s_in, uint8_t *s_out, uint2 *s_tq, const int lane) {
     const uint8_t *const src = c.src; const uint64_t n_src = c.n_src; uint8_t *const dst = c.dst; const uint8_t *const ent = c.ent;
     DecPlan *const plan = c.plan; const uint32_t nbytes = c.nbytes, nunits = c.nunits; const int bun4 = c.bun4, ush = c.ush;
@@ -124,7 +135,7 @@ __device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint
                 else for (uint32_t r = i; r < outlen; r++) s_out[r] = g[r];
             }
             wave_sync();
-            for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
+            LAB_FLUSH_USH();
             wave_sync();
         }
         else if (!bun4) wave_copy_g2g(dst + d0, g, outlen, lane);
@@ -215,9 +226,15 @@ __device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint
         if (nq == 0u && staged < slen && si + DEC_IN_MARGIN > staged) {     // move the window (queued tokens point into it)
             stage(si);
         }
+#if DEC_LEAN
+        const bool stop = dec_fill_lean(s_in, (uint32_t)shw, staged, slen, si, nq, s_tq, lane);
+        bool rewound = false;
+        ok = dec_drain<true>(s_in, shw, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
+#else
         const bool stop = dec_fill(s_in, (uint32_t)shw, staged, slen, si, nq, s_tq, lane);
         bool rewound = false;
         ok = dec_drain(s_in, shw, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
+#endif
         if (!ok) break;
         if (rewound) { slow = 2; continue; }
         if (stop) {
@@ -246,7 +263,7 @@ __device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint
     }
     // flush the chunk image
     if (ush) {
-        for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i];
+        LAB_FLUSH_USH();
     } else {
         uint8_t *o = dst + d0;
         uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);

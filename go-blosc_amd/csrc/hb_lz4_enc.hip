@@ -45,7 +45,13 @@
 #ifndef HLOG_HC
 #define HLOG_HC 8
 #endif
-#define HLOGW(WAYS) ((WAYS) == 1 ? 8 : HLOG_HC)      // log2 of the hash table's buckets: LZ4 / LZ4HC
+#ifndef ENC_HLOG
+#define ENC_HLOG 8
+#endif
+#ifndef ENC_KEY
+#define ENC_KEY 5           // bytes of a position that key the LZ4 matcher's table (5 or 6)
+#endif
+#define HLOGW(WAYS) ((WAYS) == 1 ? ENC_HLOG : HLOG_HC)      // log2 of the hash table's buckets: LZ4 / LZ4HC
 #define HSIZEW(WAYS) (1u << HLOGW(WAYS))
 #define LITCAP 32u          // literal runs up to this long are copied by the owning lane, longer ones by the wave
 
@@ -153,9 +159,55 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
     if (len & 1u) d[k] = s[k];
 }
 
+#ifndef ENC_EXT_GATE
+#define ENC_EXT_GATE 1      // bytes 12..19 of a candidate are only compared when some lane of the step still matches at 12
+#endif
+#ifndef ENC_HASH24
+#define ENC_HASH24 1
+#endif
+#ifndef ENC_NOMUL
+#define ENC_NOMUL 1
+#endif
+#ifndef ENC_GATE_HOLD
+#define ENC_GATE_HOLD 3     // run steps a full step's verdict allows (modelled: 3 keeps the far end of a float ramp at its ratio, 7 costs it 20 %)
+#endif
+#ifndef ENC_RUN_GATE
+#define ENC_RUN_GATE 48     // run step (match_chunk): taken when this many of a window's 64 bytes equal the byte before them; 0 = never
+#endif
+#ifdef ENC_DEBUG_TIMES     /* lab build only (tools/lab): clocks of the matcher's phases, summed over all wavefronts, per byte plane */
+__device__ unsigned long long g_enc_t[8][16];
+extern "C" int hblab_enc_times(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_t), sizeof(g_enc_t)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[8][16]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_enc_t), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define DBG_CLK() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#define DBG_ADD(k, v) do { dbg_acc[k] += (unsigned long long)(v); } while (0)
+#define DBG_DECL() unsigned long long dbg_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define DBG_COMMIT() do { if (lane == 0) { for (int k_ = 0; k_ < 14; k_++) if (dbg_acc[k_]) atomicAdd(&g_enc_t[dbg_plane & 7][k_], dbg_acc[k_]); } } while (0)
+#else
+#define DBG_DECL() do { } while (0)
+#define DBG_COMMIT() do { } while (0)
+#define DBG_CLK() 0ull
+#define DBG_ADD(k, v) do { } while (0)
+#endif
 #define QCAP 80             // sequence queue slots: flushed once 64 are queued, and a step adds at most 16 (matches are >= 4 bytes)
 #define SOUT 768u           // bytes of record staging per wave: drained to the record in HBM after every flush (LDS per wave
                             // sets the number of resident waves, and the matcher is latency-bound: time ~ 1 / waves)
+
+// Table index of the FIVE bytes at a position (v = bytes 0..3, v4 = bytes 4..7).  LZ4 (WAYS == 1): two 24-bit multiplies -- bytes 0..2 and
+// bytes 2..4 -- added, top byte of the sum: four full-rate instructions (a 32-bit v_mul_lo issues at a quarter of the rate; the step loop is
+// bound by instruction issue).  LZ4HC keeps round 2's multiplicative hash (its tables are larger than 256 buckets).
+template <int WAYS>
+__device__ __forceinline__ uint32_t enc_hash(const uint32_t v, const uint32_t v4) {
+#if ENC_HASH24
+    if constexpr (WAYS == 1 && ENC_HLOG == 8 && ENC_KEY == 5) {
+        const uint32_t z = __builtin_amdgcn_alignbyte(v4, v, 2u);                   // bytes 2..5
+        return (__umul24(v, 0xF85117u) + __umul24(z, 0xE01E5Bu)) >> 24;
+    }
+#endif
+    return ((v + (v4 & (ENC_KEY == 6 && WAYS == 1 ? 0xFFFFu : 255u)) * 0x50505u) * 2246822519u) >> (32 - HLOGW(WAYS));
+}
 
 // One chunk, one wavefront.  The chunk image is in LDS (byte i of the chunk at s_data[sh + i]); s_out / s_tab /
 // s_q are this wave's scratch; the record goes to `rec`, the summary to *dsc.  with_trailing: also append the
@@ -173,7 +225,8 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 template <int WAYS, int MODE>
 __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_t sh, const int len,
                                             uint8_t *s_out /* SOUT + 16 */, uint16_t *s_tab, uint2 *s_q /* {pos | len << 16, offset} */, uint32_t *s_st /* 8 words */,
-                                            ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const bool keep_long, const int accel, const int lane) {
+                                            ChunkDesc *dsc, uint8_t *rec, const bool with_trailing, const bool keep_long, const int accel, const int lane,
+                                            const int dbg_plane = 0) {
     constexpr bool SNAPPY = MODE == 1;        // MODE 0: LZ4 sequences for k_stitch, 1: Snappy elements, 2: a self-contained LZ4 block per chunk
     constexpr bool SELF = MODE == 2;
     {
@@ -184,7 +237,10 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
         }
         wave_sync();
 
-        int pos = 0, anchor = 0, nq = 0, miss = 0;
+        int pos = 0, anchor = 0, nq = 0, miss = 0, gate_left = 0;
+#ifdef LAB_ENC
+        unsigned long long lab_dummy = 0;
+#endif
         // Emission state.  It changes once per flush (every ~64 sequences), so between flushes it lives in LDS (s_st): as
         // loop-carried scalars each of these costs the step loop two register copies per step.
         int nseq = 0;                                     // sequences emitted so far
@@ -404,9 +460,19 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             if (lane + 64 < nq) s_q[lane + 64] = r1;
             st_state();
         };
-        auto flush_any = [&]() __attribute__((always_inline)) { if constexpr (SNAPPY) flush_sn(); else flush(); };
+        DBG_DECL();
+        unsigned long long dbg_flush = 0;
+        auto flush_any = [&]() __attribute__((always_inline)) {
+            const unsigned long long c0 = DBG_CLK();
+            if constexpr (SNAPPY) flush_sn(); else flush();
+            const unsigned long long c1 = DBG_CLK();
+            dbg_flush += c1 - c0; DBG_ADD(8, c1 - c0); DBG_ADD(9, 1);
+        };
+        (void)dbg_flush;
+        const unsigned long long dbg_t0 = DBG_CLK();
 
         while (pos <= mstart_max) {
+            const unsigned long long dbg_s0 = DBG_CLK(); const unsigned long long dbg_f0 = dbg_flush;
             const int p = pos + lane;
             // ---- 12 bytes at my position: 4 aligned dwords + v_alignbyte (one LDS round trip) ----
             const uint32_t ap = sh + (uint32_t)p;
@@ -422,16 +488,78 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             // inside a run of equal 4-grams <=> data[p-1] == data[p] == ... == data[p+3]
             const uint32_t vb = v & 255u;
             const uint32_t before = wave_shr1(vb, prevb);
+#if ENC_NOMUL
+            const uint32_t b4 = __builtin_amdgcn_perm(v, v, 0u);                   // byte 0 four times (a 32-bit multiply issues at a quarter of the rate)
+#else
             const uint32_t b4 = vb * 0x01010101u;
+#endif
             const unsigned long long m_first = pos > 0 ? ~0ull : ~1ull;            // p >= 1
             // bit l: data[pos+l] == data[pos+l-1]; positions past the end of the chunk hold whatever was in LDS: masked out
             const unsigned long long m_eqprev = hb_ballot(before == vb) & (len - pos >= 64 ? ~0ull : ((1ull << (len - pos)) - 1ull));
             const unsigned long long m_rle = hb_ballot(valid) & hb_ballot(v == b4) & m_eqprev & m_first;
             const bool rle = valid && (pos > 0 || lane > 0) && v == b4 && before == vb;
+#if ENC_RUN_GATE
+            if constexpr (WAYS == 1) {
+                // ---- RUN STEP.  A window in which >= ENC_RUN_GATE of the 64 bytes equal the byte before them is made of runs (a byte plane of
+                // slowly varying values): its matches are the runs themselves (offset 1), and the wave-wide mask already says where every run
+                // starts and ends -- no hash, no table probe, no candidate read, no extension, no selection walk: the selected matches are the
+                // first lanes of the groups of consecutive run lanes.  Modelled in tests/tools/gpu_lz4_model2.c: on the headline data's plane 2
+                // 51 of 55 hit steps per chunk are such steps and the ratio does not move (0.5293 -> 0.5301; all four planes 0.5169 -> 0.5161).
+                // The gate is only open for the ENC_GATE_HOLD steps behind a FULL hit step whose greedy parse needed no fewer sequences than the
+                // window has runs: where one table match spans many short runs (a periodic pattern: the low mantissa plane of a ramp, 2.7x
+                // larger with runs alone) the full steps keep it shut; and a run step still enters the first byte of every run it takes
+                // into the table, so that a full step finds such repeats at all.
+                if (gate_left > 0 && m_rle != 0ull && __builtin_popcountll(m_eqprev) >= ENC_RUN_GATE) {
+                    gate_left--;
+                    const unsigned long long sel = m_rle & ~(m_rle << 1);
+                    if (((sel >> 1) >> lane) & 1ull) {
+                        s_tab[enc_hash<WAYS>(v, v4)] = (uint16_t)p;
+                    }
+                    const unsigned long long nrun = ~(m_eqprev >> lane);
+                    const uint32_t run = nrun ? (uint32_t)__builtin_ctzll(nrun) : 64u;
+                    uint32_t ml = min(run, (uint32_t)(mend_max - p));
+                    const int lastj = 63 - __builtin_clzll(sel);
+                    const int mpj = pos + lastj, maxlj = mend_max - mpj;
+                    const int runj = (int)__builtin_amdgcn_readlane(run, lastj);
+                    int mlj = runj < maxlj ? runj : maxlj;
+                    if (lastj + runj >= 64 && mlj < maxlj) {       // the last run reaches the end of the window: go on, 256 bytes per step
+                        const uint32_t rb4 = __builtin_amdgcn_readlane(b4, lastj);
+                        for (;;) {
+                            const int i = mlj + 4 * lane;
+                            const int ic = i < maxlj ? i : maxlj;  // keep the reads inside the chunk image
+                            const uint32_t x = RD4(mpj + ic) ^ rb4;
+                            int eq = x ? (__builtin_ctz(x) >> 3) : 4;
+                            const int avail = maxlj - i;
+                            if (avail < eq) eq = avail > 0 ? avail : 0;
+                            const unsigned long long part = hb_ballot(eq != 4);
+                            if (part) {
+                                const int f = __builtin_ctzll(part);
+                                mlj += 4 * f + (int)__builtin_amdgcn_readlane((uint32_t)eq, f);
+                                break;
+                            }
+                            mlj += 256;
+                        }
+                        if (lane == lastj) ml = (uint32_t)mlj;
+                    }
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
+                    if ((sel >> lane) & 1ull) {
+                        uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = 1u;
+                        s_q[nq + rank] = e;
+                    }
+                    nq += __builtin_popcountll(sel);
+                    anchor = mpj + mlj;
+                    while (nq >= 64) flush_any();
+                    miss = 0;
+                    pos = anchor > pos + 64 ? anchor : pos + 64;
+                    DBG_ADD(2, DBG_CLK() - dbg_s0 - (dbg_flush - dbg_f0)); DBG_ADD(3, 1);
+                    continue;
+                }
+            }
+#endif
             // the table is keyed by FIVE bytes (one v_and + one v_mad_u32_u24 more than a 4-byte key): the entry of a 4-gram that
             // occurs in many contexts is then not the latest of them but the latest with the same next byte -- longer matches, 20 %
             // fewer sequences and a better ratio at the same table size (modelled in tests/tools/gpu_lz4_model.c)
-            const uint32_t h = ((v + (v4 & 255u) * 0x50505u) * 2246822519u) >> (32 - HLOGW(WAYS));
+            const uint32_t h = enc_hash<WAYS>(v, v4);
             uint32_t cand, xa, xb, ac = 0, hc_fbit = 0;
             const uint32_t *wc = nullptr;
             uint32_t c3 = 0;
@@ -500,6 +628,9 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 xa = 0; xb = 0;
             }
             unsigned long long mask = m_hit | m_rle;
+#if defined(LAB_ENC) && LAB_ENC == 2       /* lab ablation: the probe alone (no extension, selection, queue); garbage frames, timing only */
+            lab_dummy ^= mask; mask = 0; miss = -1;
+#endif
             if (mask) {
                 // An entry whose candidate still matches 12 bytes or more is put BACK: repeated content then keeps pointing
                 // at its first occurrence instead of at the previous repeat, so a decoder never finds a chain of matches
@@ -512,16 +643,25 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                     // every lane extends its own match to at most 20 bytes, branch-free (two more dwords on each side, read
                     // on this path only): v_ffbl_b32 gives -1 for 0, so the first differing bit of the 16 bytes is
                     // min(ffbl(xa), 32 + min(ffbl(xb), 32 + min(ffbl(xc), 32 + min(ffbl(xd), 32))))
-                    const uint32_t p4 = wp[4], p5 = wp[5], c4 = wc[4], c5 = wc[5];
-                    const uint32_t v12 = __builtin_amdgcn_alignbyte(p4, p3, ap & 3u), v16 = __builtin_amdgcn_alignbyte(p5, p4, ap & 3u);
-                    const uint32_t cv12 = __builtin_amdgcn_alignbyte(c4, c3, ac & 3u), cv16 = __builtin_amdgcn_alignbyte(c5, c4, ac & 3u);
-                    const uint32_t xc = hit ? (cv12 ^ v12) : (b4 ^ v12), xd = hit ? (cv16 ^ v16) : (b4 ^ v16);
-                    uint32_t fa, fb, fc, fd;
+                    uint32_t fa, fb;
                     asm("v_ffbl_b32 %0, %1" : "=v"(fa) : "v"(xa));
                     asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(xb));
-                    asm("v_ffbl_b32 %0, %1" : "=v"(fc) : "v"(xc));
-                    asm("v_ffbl_b32 %0, %1" : "=v"(fd) : "v"(xd));
-                    fbit = min(fa, min(fb, min(fc, min(fd, 32u) + 32u) + 32u) + 32u);
+#if ENC_EXT_GATE
+                    // bytes 12..19 are only looked at when some lane still matches at 12 (few-symbol planes: matches of 4-7 bytes, never)
+                    if ((hb_ballot((xa | xb) == 0u) & mask) == 0ull) {
+                        fbit = min(fa, min(fb, 32u) + 32u);
+                    } else
+#endif
+                    {
+                        const uint32_t p4 = wp[4], p5 = wp[5], c4 = wc[4], c5 = wc[5];
+                        const uint32_t v12 = __builtin_amdgcn_alignbyte(p4, p3, ap & 3u), v16 = __builtin_amdgcn_alignbyte(p5, p4, ap & 3u);
+                        const uint32_t cv12 = __builtin_amdgcn_alignbyte(c4, c3, ac & 3u), cv16 = __builtin_amdgcn_alignbyte(c5, c4, ac & 3u);
+                        const uint32_t xc = hit ? (cv12 ^ v12) : (b4 ^ v12), xd = hit ? (cv16 ^ v16) : (b4 ^ v16);
+                        uint32_t fc, fd;
+                        asm("v_ffbl_b32 %0, %1" : "=v"(fc) : "v"(xc));
+                        asm("v_ffbl_b32 %0, %1" : "=v"(fd) : "v"(xd));
+                        fbit = min(fa, min(fb, min(fc, min(fd, 32u) + 32u) + 32u) + 32u);
+                    }
                 } else {
                     fbit = hc_fbit;
                 }
@@ -599,7 +739,17 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                     last_end = pos + e;
                     mask = e >= 64 ? 0ull : (mask & (~0ull << e));
                 }
+#if ENC_RUN_GATE
+                if constexpr (WAYS == 1) {                       // the run gate's verdict (see the run step)
+                    const unsigned long long rstart = m_rle & ~(m_rle << 1);
+                    gate_left = __builtin_popcountll(rstart) <= __builtin_popcountll(sel) + 1 ? ENC_GATE_HOLD : 0;
+                }
+#endif
                 // queue the selected matches, compacted in position order
+#if defined(LAB_ENC) && LAB_ENC == 1       /* lab ablation: no queue, no emission; garbage frames, timing only */
+                lab_dummy ^= sel ^ ml ^ cand;
+                anchor = last_end;
+#else
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
                 if ((sel >> lane) & 1ull) {
                     uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = (uint32_t)p - cand;
@@ -608,15 +758,23 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 nq += __builtin_popcountll(sel);
                 anchor = last_end;
                 while (nq >= 64) flush_any();
+#endif
                 miss = 0;
+                DBG_ADD(0, DBG_CLK() - dbg_s0 - (dbg_flush - dbg_f0)); DBG_ADD(1, 1);
             } else {
                 miss++;
+                DBG_ADD(4, DBG_CLK() - dbg_s0); DBG_ADD(5, 1);
             }
             const int nxt = pos + 64 + miss * accel;            // every step without a hit widens the stride by `accel` bytes
             pos = anchor > nxt ? anchor : nxt;
         }
+        const unsigned long long dbg_t1 = DBG_CLK();
+        DBG_ADD(6, dbg_t1 - dbg_t0); DBG_ADD(7, 1);                 // the whole step loop (incl. its flushes) / chunks
         while (nq > 0) flush_any();
         ld_state();
+#ifdef LAB_ENC
+        if (lab_dummy == 0x1234567ull) s_out[lane] = 1;     // keeps the ablated computations alive
+#endif
         if constexpr (SNAPPY) {
             // the rest of the chunk is one literal element; the record is the chunk's complete element stream
             const uint32_t tl = (uint32_t)(len - anchor);
@@ -676,6 +834,8 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             *dsc = d;
         }
         wave_sync();
+        DBG_ADD(10, DBG_CLK() - dbg_t1);                            // tail: last flushes, trailing literals, descriptor
+        DBG_COMMIT();
     }
 #undef RD4
 }
@@ -766,6 +926,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
         if (!((plane_mask >> j) & 1u)) continue;           // hb_debug_plane_mask: per-plane timing
         const uint64_t e0 = (uint64_t)b * HB_CHUNK;        // first element of the block
         wave_sync();
+        const int dbg_plane = (int)j; (void)dbg_plane;
+        DBG_DECL();
+        const unsigned long long dbg_k0 = DBG_CLK(); (void)dbg_k0;
         // all loads of a batch are issued before the first use: one HBM round trip per 16 vectors, not 16
         if constexpr (TS == 2) {
             const uint32_t sel = j ? 0x07050301u : 0x06040200u;
@@ -809,7 +972,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
             }
         }
         const uint32_t ck = ck0 + j * nblk + b;
-        match_chunk<WAYS, MODE>(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, accel, lane);
+        DBG_ADD(11, DBG_CLK() - dbg_k0);                            // staging (source reads, plane extraction, LDS writes issued)
+        match_chunk<WAYS, MODE>(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, accel, lane, (int)j);
+        DBG_ADD(12, DBG_CLK() - dbg_k0); DBG_ADD(13, 1);            // the whole chunk
+        DBG_COMMIT();
     }
 }
 

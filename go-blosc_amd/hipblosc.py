@@ -12,7 +12,8 @@ import os
 from dataclasses import dataclass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhipblosc.so")
+# HIPBLOSC_LIB: another build of the same library (tools/lab/ab.py times kernel variants side by side); never a different implementation
+LIB_PATH = os.environ.get("HIPBLOSC_LIB") or os.path.join(_HERE, "lib", "libhipblosc.so")
 
 # ---- constants, blosc.go:49-52, :57-64, :89-93, :110-121 ----
 Version = "1.0.0"
