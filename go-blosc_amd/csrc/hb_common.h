@@ -29,6 +29,9 @@ __device__ __forceinline__ void st4u(uint8_t *p, uint32_t v) { ((hb_u32u *)p)->v
 // wave-wide predicate mask straight from the compare (HIP's __ballot() first materialises the predicate as 0/1:
 // v_cndmask + v_cmp per call)
 #define hb_ballot(pred) __builtin_amdgcn_ballot_w64(pred)
+// "is my lane's bit set in this WAVE-UNIFORM mask": the mask itself becomes the exec mask of the branch (s_and_saveexec on the SGPR pair),
+// where (mask >> lane) & 1 costs a 64-bit vector shift, an and and a compare per use
+#define hb_lane_in(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 
 // all lanes of the wave have finished their LDS traffic up to here, and the compiler may not
 // move LDS accesses across this point (single-wave producer/consumer through LDS).

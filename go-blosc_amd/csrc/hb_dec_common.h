@@ -169,7 +169,7 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
             si = __builtin_amdgcn_readlane(tp, jx);
             rewound = true;
         }
-        const bool istok = (amask >> lane) & 1ull;
+        const bool istok = hb_lane_in(amask);
         // a match may only read what this unit has produced (else: not ours to decide -> serial decoder)
         // (a token with mlen == 0 carries no match: the Snappy decoder queues literal elements that way)
         if (hb_ballot(istok && mlen != 0u && (offv == 0u || offv > dpos + lit + hist))) { ok = false; break; }
@@ -214,7 +214,7 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
             const unsigned long long below = pend & ((1ull << lane) - 1ull);
             const uint32_t pj = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
             const uint32_t pe = (uint32_t)__shfl((int)mend, (int)pj);
-            const bool ready = ((pend >> lane) & 1ull) && mlen <= DMCAP &&
+            const bool ready = hb_lane_in(pend) && mlen <= DMCAP &&
                                (srcend <= (int)X || below == 0ull || src0 >= (int)pe);
             if (ready) lds_match_lane(s_out, mdv, offv, mlen);
             pend &= ~hb_ballot(ready);
@@ -363,7 +363,7 @@ __device__ __forceinline__ bool dec_fill_lean(const uint8_t *s_in, const uint32_
         uint32_t cur;
         {
             const unsigned long long selfm = cmask | hb_ballot(nrel >= 64u);
-            const uint32_t succ = ((selfm >> lane) & 1ull) ? (uint32_t)lane : nrel;   // the last token of the window points at itself
+            const uint32_t succ = hb_lane_in(selfm) ? (uint32_t)lane : nrel;          // the last token of the window points at itself
             uint32_t j = 0, lastj;
             for (;;) {                                       // unrolled by 4: setting the last bit again is harmless
                 asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
@@ -382,7 +382,7 @@ __device__ __forceinline__ bool dec_fill_lean(const uint8_t *s_in, const uint32_
             if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-        if ((tmask >> lane) & 1ull) ((uint16_t *)s_tq)[nq + rank] = (uint16_t)p;
+        if (hb_lane_in(tmask)) ((uint16_t *)s_tq)[nq + rank] = (uint16_t)p;
         nq += (uint32_t)__builtin_popcountll(tmask);
         si = cur;
     }

@@ -168,6 +168,13 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 #ifndef ENC_NOMUL
 #define ENC_NOMUL 1
 #endif
+#ifndef ENC_GATE_ADAPT
+#define ENC_GATE_ADAPT 0    // 1: the verdict / hold / run-start-insert protection of the run step (measured: costs the step loop 0.13 ms of the 0.22 the run step saves)
+#endif
+#ifndef ENC_GATE_MAXRUNS
+#define ENC_GATE_MAXRUNS 7  // a run step takes at most this many runs: a window of eight or more short runs goes through the table, which sees periodic
+                            // patterns of short runs (the low mantissa plane of a float ramp: runs of 8 that repeat every 1.3 KB -- 2.7x larger as runs)
+#endif
 #ifndef ENC_GATE_HOLD
 #define ENC_GATE_HOLD 3     // run steps a full step's verdict allows (modelled: 3 keeps the far end of a float ramp at its ratio, 7 costs it 20 %)
 #endif
@@ -203,10 +210,20 @@ __device__ __forceinline__ uint32_t enc_hash(const uint32_t v, const uint32_t v4
 #if ENC_HASH24
     if constexpr (WAYS == 1 && ENC_HLOG == 8 && ENC_KEY == 5) {
         const uint32_t z = __builtin_amdgcn_alignbyte(v4, v, 2u);                   // bytes 2..5
-        return (__umul24(v, 0xF85117u) + __umul24(z, 0xE01E5Bu)) >> 24;
+        return ((uint32_t)__umul24(v, 0xF85117u) + (uint32_t)__umul24(z, 0xE01E5Bu)) >> 24;   // (this HIP declares __umul24 as int: without the casts the shift is arithmetic)
     }
 #endif
     return ((v + (v4 & (ENC_KEY == 6 && WAYS == 1 ? 0xFFFFu : 255u)) * 0x50505u) * 2246822519u) >> (32 - HLOGW(WAYS));
+}
+
+// the same index for a position whose five bytes are all the byte b (b4 = that byte four times)
+template <int WAYS>
+__device__ __forceinline__ uint32_t enc_hash_run(const uint32_t b4) {
+#if ENC_HASH24
+    if constexpr (WAYS == 1 && ENC_HLOG == 8 && ENC_KEY == 5)
+        return ((uint32_t)__umul24(b4, 0xF85117u) + (uint32_t)__umul24(b4, 0xE01E5Bu)) >> 24;
+#endif
+    return enc_hash<WAYS>(b4, b4);
 }
 
 // One chunk, one wavefront.  The chunk image is in LDS (byte i of the chunk at s_data[sh + i]); s_out / s_tab /
@@ -498,6 +515,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const unsigned long long m_eqprev = hb_ballot(before == vb) & (len - pos >= 64 ? ~0ull : ((1ull << (len - pos)) - 1ull));
             const unsigned long long m_rle = hb_ballot(valid) & hb_ballot(v == b4) & m_eqprev & m_first;
             const bool rle = valid && (pos > 0 || lane > 0) && v == b4 && before == vb;
+            bool runny = false; (void)runny;
 #if ENC_RUN_GATE
             if constexpr (WAYS == 1) {
                 // ---- RUN STEP.  A window in which >= ENC_RUN_GATE of the 64 bytes equal the byte before them is made of runs (a byte plane of
@@ -509,12 +527,14 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 // window has runs: where one table match spans many short runs (a periodic pattern: the low mantissa plane of a ramp, 2.7x
                 // larger with runs alone) the full steps keep it shut; and a run step still enters the first byte of every run it takes
                 // into the table, so that a full step finds such repeats at all.
-                if (gate_left > 0 && m_rle != 0ull && __builtin_popcountll(m_eqprev) >= ENC_RUN_GATE) {
+                runny = (int)__builtin_popcountll(m_eqprev) >= ENC_RUN_GATE;
+                const unsigned long long sel = m_rle & ~(m_rle << 1);
+                if ((!ENC_GATE_ADAPT || gate_left > 0) && m_rle != 0ull && runny && (int)__builtin_popcountll(sel) <= ENC_GATE_MAXRUNS) {
                     gate_left--;
-                    const unsigned long long sel = m_rle & ~(m_rle << 1);
-                    if (((sel >> 1) >> lane) & 1ull) {
-                        s_tab[enc_hash<WAYS>(v, v4)] = (uint16_t)p;
-                    }
+#if ENC_GATE_ADAPT && !defined(ENC_GATE_NOINS)
+                    // (the byte in front of the first run lane starts the run: its five bytes are the run's byte, so is its key)
+                    if (hb_lane_in(sel)) s_tab[enc_hash_run<WAYS>(b4)] = (uint16_t)(p - 1);
+#endif
                     const unsigned long long nrun = ~(m_eqprev >> lane);
                     const uint32_t run = nrun ? (uint32_t)__builtin_ctzll(nrun) : 64u;
                     uint32_t ml = min(run, (uint32_t)(mend_max - p));
@@ -542,7 +562,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                         if (lane == lastj) ml = (uint32_t)mlj;
                     }
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
-                    if ((sel >> lane) & 1ull) {
+                    if (hb_lane_in(sel)) {
                         uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = 1u;
                         s_q[nq + rank] = e;
                     }
@@ -739,10 +759,12 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                     last_end = pos + e;
                     mask = e >= 64 ? 0ull : (mask & (~0ull << e));
                 }
-#if ENC_RUN_GATE
-                if constexpr (WAYS == 1) {                       // the run gate's verdict (see the run step)
-                    const unsigned long long rstart = m_rle & ~(m_rle << 1);
-                    gate_left = __builtin_popcountll(rstart) <= __builtin_popcountll(sel) + 1 ? ENC_GATE_HOLD : 0;
+#if ENC_RUN_GATE && ENC_GATE_ADAPT
+                if constexpr (WAYS == 1) {                       // the run gate's verdict (see the run step): only a window of runs asks for one
+                    if (runny) {
+                        const unsigned long long rstart = m_rle & ~(m_rle << 1);
+                        gate_left = (int)__builtin_popcountll(rstart) <= (int)__builtin_popcountll(sel) + 1 ? ENC_GATE_HOLD : 0;
+                    }
                 }
 #endif
                 // queue the selected matches, compacted in position order
@@ -751,7 +773,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 anchor = last_end;
 #else
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
-                if ((sel >> lane) & 1ull) {
+                if (hb_lane_in(sel)) {
                     uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = (uint32_t)p - cand;
                     s_q[nq + rank] = e;
                 }
@@ -948,7 +970,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
             const uint32_t sel = 0x0c0c0000u | ((4u + rb) << 8) | rb;      // {lo.byte rb, hi.byte rb, 0, 0}
             constexpr int NV = TS / 4;                                      // 16-byte vectors per 4 elements
             constexpr int STEPS = (int)(HB_CHUNK / 256);
-            constexpr int BATCH = (8 / NV) < STEPS ? (8 / NV) : STEPS;     // steps per batch (<= 8 vectors in flight: 32 VGPRs, the kernel is capped at 80)
+#ifndef ENC_STAGE_VECS
+#define ENC_STAGE_VECS 8
+#endif
+            constexpr int BATCH = (ENC_STAGE_VECS / NV) < STEPS ? (ENC_STAGE_VECS / NV) : STEPS;     // steps per batch (<= 8 vectors in flight: 32 VGPRs, the kernel is capped at 80)
             static_assert(STEPS % BATCH == 0, "chunk size must be a multiple of the staging batch");
 #pragma unroll 1
             for (int it0 = 0; it0 < (int)(HB_CHUNK / 256); it0 += BATCH) {  // 4 elements (4*TS bytes) per lane per step
@@ -972,6 +997,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
             }
         }
         const uint32_t ck = ck0 + j * nblk + b;
+#if defined(LAB_ENC) && LAB_ENC == 3          /* lab ablation: staging only (garbage frames, timing only) */
+        wave_sync();
+        if (lane == 0) { ChunkDesc d0; d0.lead = 0; d0.enc_len = s_data[ck & 4095u]; d0.last_end = 0; d0.mcode0 = 0; desc[ck] = d0; }
+        continue;
+#endif
         DBG_ADD(11, DBG_CLK() - dbg_k0);                            // staging (source reads, plane extraction, LDS writes issued)
         match_chunk<WAYS, MODE>(s_data, 0u, (int)HB_CHUNK, s_out, s_tab, s_q, s_st, desc + ck, records + (size_t)ck * HB_RSTRIDE, true, false, accel, lane, (int)j);
         DBG_ADD(12, DBG_CLK() - dbg_k0); DBG_ADD(13, 1);            // the whole chunk

@@ -61,7 +61,10 @@ int main(int argc, char **argv) {
             int nrle = 0;
             for (int l = 0; l < W; l++) { const int p = pos + l; if (p > ms || p < 1) continue; const uint32_t v = rd4(d + p);
                 if (d[p - 1] == d[p] && v == (v & 255u) * 0x01010101u) nrle++; }
-            const int gated = gate && neq >= gate && gate_left > 0 && nrle > 0;
+            int nstart = 0;   /* runs the window would select: groups of consecutive run lanes */
+            { int prev = 0; for (int l = 0; l < W; l++) { const int p = pos + l; int r = 0; if (p <= ms && p >= 1) { const uint32_t v = rd4(d + p); r = d[p - 1] == d[p] && v == (v & 255u) * 0x01010101u; } if (r && !prev) nstart++; prev = r; } }
+            const int maxruns = getenv("MAXRUNS") ? atoi(getenv("MAXRUNS")) : 64;
+            const int gated = gate && neq >= gate && gate_left > 0 && nrle > 0 && nstart <= maxruns;
             if (gated) gate_left--;
             for (int half = 0; half < W; half += 64) {          /* table reads of 64 lanes, then their writes */
                 for (int l = half; l < half + 64; l++) { const int p = pos + l; cand[l] = 0; ism[l] = 0; ml[l] = 0; if (p > ms) continue; if (!gated) cand[l] = tab[HS(d + p)]; }

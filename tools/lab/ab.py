@@ -34,6 +34,8 @@ def child(a):
         shuffle, ts = int(shuffle), int(ts)
         d.src.copy_(torch.from_numpy(bench.synth_host(kind, n, 0)).view(torch.uint8))
         opts = 0 if a.no_trailer else hb.OPT_INDEX_TRAILER
+        if a.nofusion:
+            opts |= hb.OPT_NO_FUSION
         d.back.zero_()
         d.compress(shuffle, ts, opts)
         d.decompress()
@@ -68,6 +70,7 @@ def main():
     ap.add_argument("--cases", default="f32:1:4")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--no-trailer", action="store_true")
+    ap.add_argument("--nofusion", action="store_true", help="HB_OPT_NO_FUSION: separate filter passes (A/B of the fused kernels)")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -81,6 +84,8 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--mib", str(a.mib), "--cases", a.cases, "--reps", str(a.reps)]
         if a.no_trailer:
             cmd.append("--no-trailer")
+        if a.nofusion:
+            cmd.append("--nofusion")
         r = subprocess.run(cmd, env=env, capture_output=True, text=True)
         if r.returncode != 0:
             res[name] = {"error": (r.stderr or r.stdout)[-600:]}
@@ -92,12 +97,14 @@ def main():
                 print(f"{name:24s} ERROR {v}", flush=True)
                 continue
             st = v["stages"]
-            keys = ["k_match_fused", "k_match", "k_tiles", "k_scan", "k_stitch", "k_dec_plan", "k_dec_indexed", "k_dec_serial"]
-            s = " ".join(f"{k[2:]}={st[k]:.3f}" for k in keys if k in st)
+            keys = ["filter_shuffle", "filter_bitshuffle", "k_match_fused", "k_match", "k_tiles", "k_scan", "k_stitch", "k_dec_plan", "k_dec_indexed", "k_dec_serial"]
+            s = " ".join(f"{k[2:] if k.startswith('k_') else k}={st[k]:.3f}" for k in keys if k in st)
             print(f"{name:24s} {case:10s} ok={int(v['ok'])} par={v['parallel']} ratio={v['ratio']:.4f} step={v['ms_step']:.3f}ms {v['GBps']:.0f}GB/s | {s}", flush=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         json.dump(res, open(a.out, "w"), indent=1)
+    if any("error" in v for v in res.values()):
+        raise SystemExit(1)                       # a variant crashed (e.g. a GPU fault): the call must read as failed
 
 
 if __name__ == "__main__":
