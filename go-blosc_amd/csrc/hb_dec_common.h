@@ -222,7 +222,7 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
         di += total;
         if (rewound) { nq = 0; break; }
         if constexpr (LEAN) {
-            const uint16_t rest = ((const uint16_t *)s_tq)[64 + lane];  // keep what is queued beyond the 64 just decoded
+            const uint16_t rest = ((const uint16_t *)s_tq)[64 + lane < DTQ ? 64 + lane : 0];  // keep what is queued beyond the 64 just decoded
             nq -= cntb;
             if ((uint32_t)lane < nq) ((uint16_t *)s_tq)[lane] = rest;
         } else {

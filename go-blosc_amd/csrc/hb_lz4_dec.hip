@@ -68,7 +68,7 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
 }
 
 #ifndef DEC_IN_WIN
-#define DEC_IN_WIN  2560u                // bytes of a unit's stream slice that are staged in LDS at a time (the window moves)
+#define DEC_IN_WIN  1536u                // bytes of a unit's stream slice that are staged in LDS at a time (the window moves)
 #endif
 #define DEC_IN_MARGIN 320u               // a token closer than this to the end of the window is parsed after re-staging
 #define DEC_OUT_MAX HB_CHUNK             // largest output a unit may have
@@ -76,7 +76,7 @@ __global__ void k_dec_plan(const uint8_t *__restrict__ index, uint64_t index_byt
 #define DEC_LEAN 1                       // the window parser only finds the token chain; the drain parses the tokens it decodes (hb_dec_common.h)
 #endif
 #ifndef DEC_WAVES
-#define DEC_WAVES 5
+#define DEC_WAVES 6                      // with the 1.5 KiB window and the u16 token queue: 6 KiB of LDS per wave, 79 VGPRs -- 1.42 -> 1.32 ms against 5 waves and a 2.5 KiB window
 #endif
 
 // One index unit (4 KiB of output), one wavefront: everything the indexed decoder does for unit `u` of a block.  The block comes as a
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES)))
     // un-filter is fused: every unit un-shuffles its own windows before they leave the chip (dst is the final output).
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_WIN + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
-    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];     // parsed tokens waiting for their lane
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DEC_LEAN ? DTQ / 4 : DTQ];     // tokens waiting for their lane (lean: their positions, u16)
     if (plan->mode != DEC_INDEXED) return;
     const int lane = threadIdx.x;
     const uint32_t nunits = plan->nunits;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES)))
                                                     const uint32_t *__restrict__ unit_frame, uint32_t total_units) {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[DEC_IN_WIN + 128];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[DEC_OUT_MAX + 64];
-    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DEC_LEAN ? DTQ / 4 : DTQ];
     const int lane = threadIdx.x;
     for (uint32_t it = blockIdx.x; it < total_units; it += gridDim.x) {
         const uint32_t fid = unit_frame[it];

@@ -168,6 +168,9 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 #ifndef ENC_NOMUL
 #define ENC_NOMUL 1
 #endif
+#ifndef ENC_WAVES
+#define ENC_WAVES 6         // waves per SIMD the LZ4 matchers are compiled for (measured with 5.5 KiB of LDS per wave: 6 -> 1.39 ms, 7 -> 1.42, 8 -> 1.44)
+#endif
 #ifndef ENC_GATE_ADAPT
 #define ENC_GATE_ADAPT 0    // 1: the verdict / hold / run-start-insert protection of the run step (measured: costs the step loop 0.13 ms of the 0.22 the run step saves)
 #endif
@@ -317,10 +320,15 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t prev = wave_shr1(end, batch_anchor);
             const uint32_t lit = q_mp - prev, mcode = q_ml - 4u;
             const bool first = !SELF && (nseq == 0) && lane == 0;  // sequence 0 of the chunk: token comes from k_stitch (not when the chunk is a block of its own)
-            const uint32_t nbl = first ? 0u : lz4_ext_bytes(lit), nbm = lz4_ext_bytes(mcode);
+            const uint32_t nbl = first ? 0u : lz4_ext_bytes16(lit), nbm = lz4_ext_bytes16(mcode);      // (both below 4096 + 15: chunk-local)
             const uint32_t size = lane < take ? ((first ? 0u : 1u) + nbl + lit + 2u + nbm) : 0u;
             const uint32_t incl = wave_incl_scan_dpp(size);
             int cnt = __builtin_popcountll(hb_ballot(lane < take && incl <= SOUT - opend));
+            // what is queued beyond the sequences emitted now is read BEFORE anything is staged: the queue lives in the staging buffer's bytes
+            // (s_q = s_out + 16: the two are never in use at the same time, and 640 bytes less LDS per wave are three more waves per CU)
+            const uint32_t i0 = (uint32_t)(lane + (cnt ? cnt : 1)), i1 = i0 + 64u;
+            const uint2 r0 = s_q[i0 < QCAP ? i0 : 0], r1 = s_q[i1 < QCAP ? i1 : 0];
+            wave_sync();
             if (nseq == 0) {
                 lead = __builtin_amdgcn_readlane(lit, 0);
                 const uint32_t m0 = __builtin_amdgcn_readlane(mcode, 0);
@@ -354,7 +362,11 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             } else {
                 const bool act = lane < cnt;
                 uint32_t q = opend + incl - size;
-                uint32_t litdst = 0;
+                const uint32_t litdst = q + (first ? 0u : 1u + nbl);
+                // (measured and not kept: runs of 1..8 literals copied blind -- one unaligned 8-byte read, one or two unaligned 4-byte stores in front
+                // of the token / offset stores -- instead of the exact-length pieces: 1.405 against 1.383 ms, the replayed unaligned accesses cost
+                // what the saved exec-mask branches gain)
+                if (act && lit <= LITCAP) lds_copy_exact(s_out + litdst, data + prev, lit);
                 if (act) {
                     if (!first) {
                         s_out[q++] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (mcode < 15u ? mcode : 15u));
@@ -363,8 +375,6 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                             s_out[q++] = (uint8_t)((lit - 15u) - 255u * (nbl - 1));
                         }
                     }
-                    litdst = q;
-                    if (lit <= LITCAP) lds_copy_exact(s_out + q, data + prev, lit);
                     q += lit;
                     ((hb_u16u *)(s_out + q))->v = (uint16_t)q_off;
                     q += 2;
@@ -388,10 +398,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             }
             batch_anchor = __builtin_amdgcn_readlane(end, cnt - 1);
             nseq += cnt;
-            // keep what is queued beyond the sequences just emitted
-            const uint32_t i0 = (uint32_t)(lane + cnt), i1 = i0 + 64u;
-            const uint2 r0 = s_q[i0 < QCAP ? i0 : 0], r1 = s_q[i1 < QCAP ? i1 : 0];
-            drain(false);                                      // (its wave_sync also orders the queue reads before the writes)
+            drain(false);
             nq -= cnt;
             if (lane < nq) s_q[lane] = r0;
             if (lane + 64 < nq) s_q[lane + 64] = r1;
@@ -433,6 +440,9 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t size = lane < take ? lh + lit + csz : 0u;
             const uint32_t incl = wave_incl_scan_dpp(size);
             int cnt = __builtin_popcountll(hb_ballot(lane < take && incl <= SOUT - opend));
+            const uint32_t i0 = (uint32_t)(lane + (cnt ? cnt : 1)), i1 = i0 + 64u;     // (as in flush(): the queue shares the staging buffer's bytes)
+            const uint2 r0 = s_q[i0 < QCAP ? i0 : 0], r1 = s_q[i1 < QCAP ? i1 : 0];
+            wave_sync();
             if (cnt == 0) {                                        // a literal run longer than the staging buffer: header, pieces, copies
                 cnt = 1;
                 uint32_t hl = 0;
@@ -469,8 +479,6 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             }
             batch_anchor = __builtin_amdgcn_readlane(end, cnt - 1);
             nseq += cnt;
-            const uint32_t i0 = (uint32_t)(lane + cnt), i1 = i0 + 64u;
-            const uint2 r0 = s_q[i0 < QCAP ? i0 : 0], r1 = s_q[i1 < QCAP ? i1 : 0];
             drain(false);
             nq -= cnt;
             if (lane < nq) s_q[lane] = r0;
@@ -872,9 +880,10 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src_, 
                                               uint32_t nchunks, int bits4, int keep_long, int accel,
                                               const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ chunk_frame) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];       // record staging; its bytes 16.. double as the sequence queue between flushes
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
-    __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
+    static_assert(16 + QCAP * 8 <= SOUT + 16, "the sequence queue must fit into the staging buffer");
+    uint2 *const s_q = (uint2 *)(s_out + 16);
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
     uint32_t *const s_st = (uint32_t *)(s_data + HB_CHUNK + 80);
@@ -915,13 +924,14 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src_, 
 // workgroup ids that are equal mod 8 (same XCD under round-robin placement: they share the L2 lines -- speed
 // only) and are otherwise independent: planes differ a lot in cost, a barrier between them would idle the cheap ones.
 template <int TS, int WAYS, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 6 : 4))) void k_match_fused(const uint8_t *__restrict__ src_, ChunkDesc *__restrict__ desc,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? ENC_WAVES : 4))) void k_match_fused(const uint8_t *__restrict__ src_, ChunkDesc *__restrict__ desc,
                                                     uint8_t *__restrict__ records, uint32_t nblk_, uint32_t plane_mask, int accel,
                                                     const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ chunk_frame, uint32_t total_) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];       // record staging; its bytes 16.. double as the sequence queue between flushes
     __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
-    __shared__ __attribute__((aligned(16))) uint2 s_q[QCAP];
+    static_assert(16 + QCAP * 8 <= SOUT + 16, "the sequence queue must fit into the staging buffer");
+    uint2 *const s_q = (uint2 *)(s_out + 16);
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
     uint32_t *const s_st = (uint32_t *)(s_data + HB_CHUNK + 80);
@@ -1141,6 +1151,14 @@ __global__ __launch_bounds__(256) void k_scan(const Agg *__restrict__ tile_agg, 
 // ----------------------------------------------------------------------------------------------
 // k_stitch: one workgroup (16 waves) per tile of 256 chunks; wave w places chunks w, w+16, ...
 // ----------------------------------------------------------------------------------------------
+#ifndef STITCH_NT
+#define STITCH_NT 0     // (measured: nontemporal copies in k_stitch 0.249 -> 0.265 ms)
+#endif
+#if STITCH_NT
+#define STITCH_COPY wave_copy_g2g_nt
+#else
+#define STITCH_COPY wave_copy_g2g
+#endif
 #define STITCH_THREADS 512     /* measured: 1024 -> 0.29 ms, 512 -> 0.25 ms, 256 -> 0.36 ms per GiB */
 __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
         const ChunkDesc *__restrict__ desc, const uint8_t *__restrict__ records, const uint8_t *__restrict__ src,
@@ -1221,14 +1239,14 @@ __global__ __launch_bounds__(STITCH_THREADS) void k_stitch(
             const uint32_t hdr = 1 + lz4_ext_bytes(tl);
             const uint32_t carry_lits = start - a;
             wave_write_lit_header(out + O, tl, cd.mcode0, lane);
-            wave_copy_g2g(out + O + hdr + carry_lits, records + (size_t)ck * HB_RSTRIDE, cd.enc_len, lane);
+            STITCH_COPY(out + O + hdr + carry_lits, records + (size_t)ck * HB_RSTRIDE, cd.enc_len, lane);
             I = O + hdr + carry_lits + cd.enc_len;
             a2 = start + cd.last_end; tpos = a2;
         }
         // trailing literals (from the source, or from the record when the filter was fused): part of the run that ends at NF
         const uint32_t hdr2 = 1 + lz4_ext_bytes(NF - a2);
         const uint8_t *lsrc = lit_from_records ? records + (size_t)ck * HB_RSTRIDE + (cd.last_end ? cd.enc_len : 0u) : src + tpos;
-        wave_copy_g2g(out + I + hdr2 + (tpos - a2), lsrc, end - tpos, lane);
+        STITCH_COPY(out + I + hdr2 + (tpos - a2), lsrc, end - tpos, lane);
         if (ck + 1 == nchunks) wave_write_lit_header(out + I, NF - a2, 0, lane);  // final literal-only sequence
         if (index && lane == 0) {
             uint32_t *e = (uint32_t *)(index + HB_IDX_HDR_BYTES) + 4 * (size_t)ck;
