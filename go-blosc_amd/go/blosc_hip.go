@@ -351,8 +351,24 @@ func DecompressFrames(frames [][]byte) (out [][]byte, errs []error) {
 
 // PinnedBytes returns a []byte backed by hb_host_alloc memory (free with FreePinned).  It holds no Go pointers
 // and is not moved by the GC, so the library may keep its address across the Submit/Wait pair.
-func PinnedBytes(n int) []byte  { return unsafe.Slice((*byte)(C.hb_host_alloc(C.size_t(n))), n) }
-func FreePinned(b []byte)       { C.hb_host_free(unsafe.Pointer(&b[0])) }
+// A failed allocation (hipHostMalloc refused: n == 0, or the pinned pool is exhausted) returns nil, never a slice over a nil pointer.
+func PinnedBytes(n int) []byte {
+	if n <= 0 {
+		return nil
+	}
+	p := C.hb_host_alloc(C.size_t(n))
+	if p == nil {
+		return nil
+	}
+	return unsafe.Slice((*byte)(p), n)
+}
+
+// FreePinned releases a slice returned by PinnedBytes (nil / empty: nothing to do).
+func FreePinned(b []byte) {
+	if len(b) > 0 {
+		C.hb_host_free(unsafe.Pointer(&b[0]))
+	}
+}
 
 type FrameQueue struct{ q *C.hb_queue }
 

@@ -58,6 +58,12 @@ def test_simd_table_kats_on_device(hb):
     check_simd_table_kats(lambda b: hb.shuffleBytes(b, 4), lambda b: hb.unshuffleBytes(b, 4))
 
 
+def test_bitshuffle_asm_kats_on_device(hb):
+    # the vectors computed from the reference's own bitShuffleAVX2 / bitUnshuffleAVX2 instruction streams (tests/golden/make_bitshuffle_asm_kat.py)
+    from test_oracle import check_bitshuffle_asm_kats
+    check_bitshuffle_asm_kats(lambda b, ts: hb.bitShuffle(b, ts), lambda b, ts: hb.bitUnshuffle(b, ts))
+
+
 def test_noop_cases(hb):
     # typeSize <= 1 or len < typeSize returns the input (shuffle.go:17-19, shuffle_test.go:318-380)
     x = bytes(range(7))

@@ -60,6 +60,44 @@ def check_simd_table_kats(shuffle, unshuffle):
         assert back == src
 
 
+def _kat_input(kind, n):
+    """the two input generators of tests/golden/make_bitshuffle_asm_kat.py (numbers, restated: the script itself needs /root/reference)"""
+    if kind == "i%256":
+        return bytes(i % 256 for i in range(n))
+    out, z, m = bytearray(), 0x9E3779B97F4A7C15, (1 << 64) - 1
+    while len(out) < n:
+        z = (z + 0x9E3779B97F4A7C15) & m
+        x = z
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+        x ^= x >> 31
+        out += x.to_bytes(8, "little")
+    return bytes(out[:n])
+
+
+def check_bitshuffle_asm_kats(bitshuffle, bitunshuffle):
+    """The reference-held pin of bitShuffle / bitUnshuffle for every typesize: vectors computed by interpreting the instruction stream of the
+    reference's own bitShuffleAVX2 / bitUnshuffleAVX2 (tests/golden/make_bitshuffle_asm_kat.py; shuffle_amd64.s:346-875, :879-1394), which
+    the reference requires to agree with its scalar loop (shuffle.go:156-173).  The candidate must write exactly the routine's bytes over
+    the whole groups it handles, leave the partial group and the tail verbatim (what the Go caller does behind a `true`), and invert it."""
+    doc = json.load(open(os.path.join(HERE, "golden", "bitshuffle_asm_kat.json")))
+    assert len(doc["vectors"]) >= 12
+    for v in doc["vectors"]:
+        src = _kat_input(v["input"], v["n"])
+        ts, p = v["typesize"], v["prefix_bytes"]
+        got = bitshuffle(src, ts)
+        assert len(got) == v["n"]
+        assert got[:p].hex() == v["bitshuffle_prefix_hex"], (v["input"], v["n"], ts)
+        if v["returns"]:
+            assert got[p:] == src[p:], (v["input"], v["n"], ts)                  # shuffle.go:162-173
+        assert bitunshuffle(got, ts) == src, (v["input"], v["n"], ts)
+
+
+def test_bitshuffle_asm_kats(O):
+    check_bitshuffle_asm_kats(lambda b, ts: O.filter(OPS["bitshuffle"], np.frombuffer(b, np.uint8), ts).tobytes(),
+                              lambda b, ts: O.filter(OPS["bitunshuffle"], np.frombuffer(b, np.uint8), ts).tobytes())
+
+
 def test_simd_table_kats(O):
     check_simd_table_kats(lambda b: O.filter(OPS["shuffle"], np.frombuffer(b, np.uint8), 4).tobytes(),
                           lambda b: O.filter(OPS["unshuffle"], np.frombuffer(b, np.uint8), 4).tobytes())
