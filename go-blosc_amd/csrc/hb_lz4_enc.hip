@@ -41,6 +41,7 @@
 #include "hb_lz4.h"
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 
 #ifndef HLOG_HC
 #define HLOG_HC 8
@@ -167,6 +168,9 @@ __device__ __forceinline__ void lds_copy_exact(uint8_t *d, const uint8_t *s, uin
 #endif
 #ifndef ENC_NOMUL
 #define ENC_NOMUL 1
+#endif
+#ifndef ENC_INNER_STEP
+#define ENC_INNER_STEP 1
 #endif
 #ifndef ENC_WAVES
 #define ENC_WAVES 6         // waves per SIMD the LZ4 matchers are compiled for (measured with 5.5 KiB of LDS per wave: 6 -> 1.39 ms, 7 -> 1.42, 8 -> 1.44)
@@ -494,10 +498,13 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             dbg_flush += c1 - c0; DBG_ADD(8, c1 - c0); DBG_ADD(9, 1);
         };
         (void)dbg_flush;
-        const unsigned long long dbg_t0 = DBG_CLK();
+        const unsigned long long dbg_t0 = DBG_CLK(); (void)dbg_t0;
 
-        while (pos <= mstart_max) {
-            const unsigned long long dbg_s0 = DBG_CLK(); const unsigned long long dbg_f0 = dbg_flush;
+        // One step = 64 positions.  The body exists twice: INNER for the steps whose positions and 20-byte extensions all lie inside the chunk
+        // (all but the first and the last one or two of a chunk: no validity masks, no clamping against the end), and the general one.
+        auto step = [&](auto inner_tag) __attribute__((always_inline)) {
+            constexpr bool INNER = decltype(inner_tag)::value;
+            const unsigned long long dbg_s0 = DBG_CLK(); const unsigned long long dbg_f0 = dbg_flush; (void)dbg_s0; (void)dbg_f0;
             const int p = pos + lane;
             // ---- 12 bytes at my position: 4 aligned dwords + v_alignbyte (one LDS round trip) ----
             const uint32_t ap = sh + (uint32_t)p;
@@ -509,7 +516,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             const uint32_t v8 = __builtin_amdgcn_alignbyte(p3, p2, ap & 3u);
             // predicates are kept as wave masks (one v_cmp each, combined on the scalar side): a ballot of a compound
             // bool would first be materialised per lane
-            const bool valid = p <= mstart_max;
+            const bool valid = INNER || p <= mstart_max;       // INNER: a step whose 64 positions and their 20-byte extensions lie inside the chunk
             // inside a run of equal 4-grams <=> data[p-1] == data[p] == ... == data[p+3]
             const uint32_t vb = v & 255u;
             const uint32_t before = wave_shr1(vb, prevb);
@@ -518,11 +525,11 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
 #else
             const uint32_t b4 = vb * 0x01010101u;
 #endif
-            const unsigned long long m_first = pos > 0 ? ~0ull : ~1ull;            // p >= 1
+            const unsigned long long m_first = INNER || pos > 0 ? ~0ull : ~1ull;   // p >= 1
             // bit l: data[pos+l] == data[pos+l-1]; positions past the end of the chunk hold whatever was in LDS: masked out
-            const unsigned long long m_eqprev = hb_ballot(before == vb) & (len - pos >= 64 ? ~0ull : ((1ull << (len - pos)) - 1ull));
+            const unsigned long long m_eqprev = hb_ballot(before == vb) & (INNER || len - pos >= 64 ? ~0ull : ((1ull << (len - pos)) - 1ull));
             const unsigned long long m_rle = hb_ballot(valid) & hb_ballot(v == b4) & m_eqprev & m_first;
-            const bool rle = valid && (pos > 0 || lane > 0) && v == b4 && before == vb;
+            const bool rle = valid && (INNER || pos > 0 || lane > 0) && v == b4 && before == vb;
             bool runny = false; (void)runny;
 #if ENC_RUN_GATE
             if constexpr (WAYS == 1) {
@@ -580,7 +587,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                     miss = 0;
                     pos = anchor > pos + 64 ? anchor : pos + 64;
                     DBG_ADD(2, DBG_CLK() - dbg_s0 - (dbg_flush - dbg_f0)); DBG_ADD(3, 1);
-                    continue;
+                    return;
                 }
             }
 #endif
@@ -695,8 +702,8 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 }
                 uint32_t ml = 4u + (fbit >> 3);
                 const uint32_t maxl = (uint32_t)(mend_max - p);
-                unsigned long long lmask = mask & hb_ballot(fbit == 128u) & hb_ballot(ml < maxl);
-                ml = min(ml, maxl);
+                unsigned long long lmask = mask & hb_ballot(fbit == 128u);
+                if constexpr (!INNER) { lmask &= hb_ballot(ml < maxl); ml = min(ml, maxl); }      // (INNER: ml <= 20 < maxl)
                 if (lmask & m_rle & ~m_hit) {
                     // a run: the offset-1 match is the rest of the run, and the wave already knows where runs end as far
                     // as this window goes -- only a run that leaves the window needs the cooperative extension
@@ -797,8 +804,11 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             }
             const int nxt = pos + 64 + miss * accel;            // every step without a hit widens the stride by `accel` bytes
             pos = anchor > nxt ? anchor : nxt;
+                };
+        while (pos <= mstart_max) {
+            if (ENC_INNER_STEP && pos > 0 && pos + 80 <= mstart_max) step(std::true_type{}); else step(std::false_type{});
         }
-        const unsigned long long dbg_t1 = DBG_CLK();
+        const unsigned long long dbg_t1 = DBG_CLK(); (void)dbg_t1;
         DBG_ADD(6, dbg_t1 - dbg_t0); DBG_ADD(7, 1);                 // the whole step loop (incl. its flushes) / chunks
         while (nq > 0) flush_any();
         ld_state();
