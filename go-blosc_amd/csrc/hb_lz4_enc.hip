@@ -542,9 +542,14 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 // window has runs: where one table match spans many short runs (a periodic pattern: the low mantissa plane of a ramp, 2.7x
                 // larger with runs alone) the full steps keep it shut; and a run step still enters the first byte of every run it takes
                 // into the table, so that a full step finds such repeats at all.
-                runny = (int)__builtin_popcountll(m_eqprev) >= ENC_RUN_GATE;
+                // (population counts through the scalar instruction by hand: the compiler turns `popcount(mask) >= 48` into a 64-bit VECTOR compare)
+                uint32_t n_eq, n_runs;
+                asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n_eq) : "s"(m_eqprev) : "scc");
+                runny = n_eq >= (uint32_t)ENC_RUN_GATE;
                 const unsigned long long sel = m_rle & ~(m_rle << 1);
-                if ((!ENC_GATE_ADAPT || gate_left > 0) && m_rle != 0ull && runny && (int)__builtin_popcountll(sel) <= ENC_GATE_MAXRUNS) {
+                n_runs = 64u;
+                if (runny) asm volatile("s_bcnt1_i32_b64 %0, %1" : "=s"(n_runs) : "s"(sel) : "scc");      // (volatile: keeps the test behind the first branch -- most steps leave there)
+                if ((!ENC_GATE_ADAPT || gate_left > 0) && n_runs <= (uint32_t)ENC_GATE_MAXRUNS && m_rle != 0ull) {
                     gate_left--;
 #if ENC_GATE_ADAPT && !defined(ENC_GATE_NOINS)
                     // (the byte in front of the first run lane starts the run: its five bytes are the run's byte, so is its key)
