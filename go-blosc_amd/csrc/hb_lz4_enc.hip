@@ -582,9 +582,10 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                         if (lane == lastj) ml = (uint32_t)mlj;
                     }
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
-                    if (hb_lane_in(sel)) {
+                    {   // every lane stores: the lanes that are not selected to the spare slot behind the queue (a v_cndmask on the mask itself where
+                        // a predicated store costs three scalar instructions -- the step loop issues as many scalar as vector instructions)
                         uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = 1u;
-                        s_q[nq + rank] = e;
+                        s_q[hb_lane_in(sel) ? (uint32_t)nq + rank : (uint32_t)QCAP] = e;
                     }
                     nq += __builtin_popcountll(sel);
                     anchor = mpj + mlj;
@@ -607,7 +608,8 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
             unsigned long long m_hit;
             if constexpr (WAYS == 1) {
                 cand = s_tab[h];
-                if (valid && !rle) s_tab[h] = (uint16_t)p;
+                if constexpr (INNER) s_tab[hb_lane_in(m_rle) ? HSIZEW(WAYS) * WAYS : h] = (uint16_t)p;      // (run lanes store to the spare entry behind the table)
+                else if (valid && !rle) s_tab[h] = (uint16_t)p;
                 // ---- 12 bytes at the candidate (second round trip) ----
                 ac = sh + cand;
                 wc = (const uint32_t *)s_data + (ac >> 2);
@@ -793,26 +795,29 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 anchor = last_end;
 #else
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
-                if (hb_lane_in(sel)) {
+                {
                     uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = (uint32_t)p - cand;
-                    s_q[nq + rank] = e;
+                    s_q[hb_lane_in(sel) ? (uint32_t)nq + rank : (uint32_t)QCAP] = e;       // (the spare slot: see the run step)
                 }
                 nq += __builtin_popcountll(sel);
                 anchor = last_end;
                 while (nq >= 64) flush_any();
 #endif
                 miss = 0;
+                pos = anchor > pos + 64 ? anchor : pos + 64;
                 DBG_ADD(0, DBG_CLK() - dbg_s0 - (dbg_flush - dbg_f0)); DBG_ADD(1, 1);
             } else {
                 miss++;
+                const int nxt = pos + 64 + miss * accel;        // every step without a hit widens the stride by `accel` bytes
+                pos = anchor > nxt ? anchor : nxt;
                 DBG_ADD(4, DBG_CLK() - dbg_s0); DBG_ADD(5, 1);
             }
-            const int nxt = pos + 64 + miss * accel;            // every step without a hit widens the stride by `accel` bytes
-            pos = anchor > nxt ? anchor : nxt;
                 };
-        while (pos <= mstart_max) {
-            if (ENC_INNER_STEP && pos > 0 && pos + 80 <= mstart_max) step(std::true_type{}); else step(std::false_type{});
+        if (ENC_INNER_STEP) {
+            if (pos <= mstart_max) step(std::false_type{});                              // (pos == 0)
+            while (pos + 80 <= mstart_max) step(std::true_type{});                       // (pos > 0 from here on: a step advances by at least 64)
         }
+        while (pos <= mstart_max) step(std::false_type{});
         const unsigned long long dbg_t1 = DBG_CLK(); (void)dbg_t1;
         DBG_ADD(6, dbg_t1 - dbg_t0); DBG_ADD(7, 1);                 // the whole step loop (incl. its flushes) / chunks
         while (nq > 0) flush_any();
@@ -896,8 +901,8 @@ __global__ __launch_bounds__(64) void k_match(const uint8_t *__restrict__ src_, 
                                               const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ chunk_frame) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];       // record staging; its bytes 16.. double as the sequence queue between flushes
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
-    static_assert(16 + QCAP * 8 <= SOUT + 16, "the sequence queue must fit into the staging buffer");
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS + 8];         // (+ a spare entry: the store of lanes that insert nothing)
+    static_assert(16 + (QCAP + 1) * 8 <= SOUT + 16, "the sequence queue (+ its spare slot) must fit into the staging buffer");
     uint2 *const s_q = (uint2 *)(s_out + 16);
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
@@ -944,8 +949,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAYS == 1 ? 
                                                     const BatchFrame *__restrict__ bf, const uint32_t *__restrict__ chunk_frame, uint32_t total_) {
     __shared__ __attribute__((aligned(16))) uint8_t s_data[HB_CHUNK + 112];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[SOUT + 16];       // record staging; its bytes 16.. double as the sequence queue between flushes
-    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS];
-    static_assert(16 + QCAP * 8 <= SOUT + 16, "the sequence queue must fit into the staging buffer");
+    __shared__ __attribute__((aligned(16))) uint16_t s_tab[HSIZEW(WAYS) * WAYS + 8];         // (+ a spare entry: the store of lanes that insert nothing)
+    static_assert(16 + (QCAP + 1) * 8 <= SOUT + 16, "the sequence queue (+ its spare slot) must fit into the staging buffer");
     uint2 *const s_q = (uint2 *)(s_out + 16);
     // emission state: the last 32 bytes of s_data's slack (read as data only by lanes past the end of the chunk, never
     // staged over) -- LDS is allocated in 512-byte granules and 13 of them give 24 waves per CU
