@@ -32,6 +32,13 @@ __device__ __forceinline__ void st4u(uint8_t *p, uint32_t v) { ((hb_u32u *)p)->v
 // "is my lane's bit set in this WAVE-UNIFORM mask": the mask itself becomes the exec mask of the branch (s_and_saveexec on the SGPR pair),
 // where (mask >> lane) & 1 costs a 64-bit vector shift, an and and a compare per use
 #define hb_lane_in(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
+// mask[lane] ? a : b as ONE v_cndmask on the scalar mask (left to itself the compiler sinks the computation of `a` into an exec-masked
+// block: two scalar instructions more, and the LZ4 step loops issue as many scalar as vector instructions)
+__device__ __forceinline__ uint32_t hb_select_lane(unsigned long long mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
 
 // all lanes of the wave have finished their LDS traffic up to here, and the compiler may not
 // move LDS accesses across this point (single-wave producer/consumer through LDS).

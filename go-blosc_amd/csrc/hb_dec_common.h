@@ -38,6 +38,12 @@ struct DecBatchFrame {
 size_t hb_lz4_dec_batch_units(int nframes, const DecBatchFrame *h, uint32_t *unit0_out);
 int hb_launch_lz4_decode_batch_indexed(int nframes, const DecBatchFrame *d_bf, uint32_t *d_unit_frame, uint32_t total_units, int any_ush, hipStream_t s);
 
+#ifndef DEC_BPERM_WALK
+#define DEC_BPERM_WALK 1
+#endif
+#ifndef DEC_BPERM_MIN
+#define DEC_BPERM_MIN 8u                 // tokens in the previous window from which the chain is followed by pointer doubling (dec_fill_lean)
+#endif
 #ifndef DTQ
 #define DTQ 96                           // token queue slots: < 64 queued before a window is parsed; a 64-byte window adds <= 22 LZ4 tokens or <= 32 Snappy elements
 #endif
@@ -224,7 +230,7 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
         if constexpr (LEAN) {
             const uint16_t rest = ((const uint16_t *)s_tq)[64 + lane < DTQ ? 64 + lane : 0];  // keep what is queued beyond the 64 just decoded
             nq -= cntb;
-            if ((uint32_t)lane < nq) ((uint16_t *)s_tq)[lane] = rest;
+            ((uint16_t *)s_tq)[lane] = rest;                    // (every lane: the slots behind nq are free)
         } else {
             const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
             nq -= cntb;
@@ -348,8 +354,12 @@ __device__ __forceinline__ bool dec_fill(const uint8_t *s_in, const uint32_t sh,
 // the positions of the real tokens (u16); dec_drain<true> parses the fields of the 64 tokens it decodes.  An extension byte is taken to
 // be the only one here; dec_drain<true> looks at it and rewinds at a token where that does not hold.
 __device__ __forceinline__ bool dec_fill_lean(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, const uint32_t slen,
-                                              uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+                                              uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane, uint32_t &last_ntok) {
     bool stop = false;
+    // which of the two ways to follow the chain a window takes is decided by the window before it: the doubling costs nine ds_bpermute whatever the
+    // window holds, the scalar walk three instructions per token (bit-shuffled integers: 3 tokens per window -- 1.07 ms against 1.32 with the doubling
+    // everywhere; the headline's dense planes: 14 per window, 1.32 against 1.28)
+    // (last_ntok: the caller's, carried from call to call; it starts a unit at DEC_BPERM_MIN)
     while (nq < 64u && !stop) {
         if (si == slen) { stop = true; break; }
         const uint32_t base = si, p = base + (uint32_t)lane;
@@ -361,9 +371,40 @@ __device__ __forceinline__ bool dec_fill_lean(const uint8_t *s_in, const uint32_
         const unsigned long long cmask = hb_ballot(p + len + 1u > lim);
         unsigned long long tmask = 0;
         uint32_t cur;
+        const unsigned long long selfm = cmask | hb_ballot(nrel >= 64u);
+        const uint32_t succ = hb_lane_in(selfm) ? (uint32_t)lane : nrel;              // the last token of the window points at itself
+#if DEC_BPERM_WALK
+        if (last_ntok >= DEC_BPERM_MIN) {
+            // The chain WITHOUT a scalar walk (one s_bitset + s_nop + v_readlane per token: the decoder issues more scalar than vector
+            // instructions, and half of them were this walk): successor tables by pointer doubling (S2 = S1 o S1, ... S16: four
+            // ds_bpermute), then lane k composes the powers its bits name -- c_k = S1^k(lane 0), five more -- and holds the k-th token of
+            // the window: the queue is written compacted, no rank computation either.  A window holds at most 22 tokens (3 bytes each).
+            const uint32_t s1 = succ;
+            const uint32_t s2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s1 << 2), (int)s1);
+            const uint32_t s4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s2 << 2), (int)s2);
+            const uint32_t s8 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s4 << 2), (int)s4);
+            const uint32_t s16 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s8 << 2), (int)s8);
+            uint32_t c = 0;
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s1); c = (lane & 1) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s2); c = (lane & 2) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s4); c = (lane & 4) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s8); c = (lane & 8) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s16); c = (lane & 16) ? y : c; }
+            // c_k repeats once the chain has reached its last lane: the tokens are the lanes whose c differs from their left neighbour's
+            const uint32_t left = wave_shr1(c, 0xFFFFFFFFu);
+            const unsigned long long distinct = hb_ballot(c != left) | 0xFFFFFFFF00000000ull;   // (lanes 32.. take no part)
+            uint32_t ntok = (uint32_t)__builtin_ctzll(~distinct | (1ull << 32));                 // leading run of distinct lanes (lane 0 always is)
+            const uint32_t lastj = __builtin_amdgcn_readlane(c, (int)ntok - 1);
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            if ((cmask >> lastj) & 1ull) { ntok--; cur = base + lastj; stop = true; }           // a token this parser does not take ends the walk
+            ((uint16_t *)s_tq)[(uint32_t)lane < ntok ? nq + (uint32_t)lane : (uint32_t)(DTQ - 1)] = (uint16_t)(base + c);
+            nq += ntok;
+            si = cur;
+            last_ntok = ntok;
+            continue;
+        }
+#endif
         {
-            const unsigned long long selfm = cmask | hb_ballot(nrel >= 64u);
-            const uint32_t succ = hb_lane_in(selfm) ? (uint32_t)lane : nrel;          // the last token of the window points at itself
             uint32_t j = 0, lastj;
             for (;;) {                                       // unrolled by 4: setting the last bit again is harmless
                 asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
@@ -382,8 +423,9 @@ __device__ __forceinline__ bool dec_fill_lean(const uint8_t *s_in, const uint32_
             if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-        if (hb_lane_in(tmask)) ((uint16_t *)s_tq)[nq + rank] = (uint16_t)p;
-        nq += (uint32_t)__builtin_popcountll(tmask);
+        ((uint16_t *)s_tq)[hb_select_lane(tmask, nq + rank, (uint32_t)(DTQ - 1))] = (uint16_t)p;
+        last_ntok = (uint32_t)__builtin_popcountll(tmask);
+        nq += last_ntok;
         si = cur;
     }
     return stop;

@@ -96,7 +96,14 @@ struct DecCtx {
 #elif defined(LAB_DEC_FLUSH) && LAB_DEC_FLUSH == 2
 #define LAB_FLUSH_USH() do { for (uint32_t i = lane * 16u; i < outlen; i += 1024u) st16u(dst + d0 + i, *(const u32x4 *)(s_out + i)); } while (0)
 #else
-#define LAB_FLUSH_USH() do { for (uint32_t i = lane; i < outlen; i += 64) udst[(size_t)i * (uint32_t)ush] = s_out[i]; } while (0)
+// (unrolled by eight: the loop control of 64 single-byte rounds is 200 scalar instructions per unit otherwise -- the decoder issues more scalar than vector instructions)
+#define LAB_FLUSH_USH() do { \
+        uint32_t i_ = lane; \
+        for (; i_ + 448u < outlen; i_ += 512u) { \
+            _Pragma("unroll") for (uint32_t k_ = 0; k_ < 8u; k_++) udst[(size_t)(i_ + 64u * k_) * (uint32_t)ush] = s_out[i_ + 64u * k_]; \
+        } \
+        for (; i_ < outlen; i_ += 64) udst[(size_t)i_ * (uint32_t)ush] = s_out[i_]; \
+    } while (0)
 #endif
 __device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint8_t *s_in, uint8_t *s_out, uint2 *s_tq, const int lane) {
     const uint8_t *const src = c.src; const uint64_t n_src = c.n_src; uint8_t *const dst = c.dst; const uint8_t *const ent = c.ent;
@@ -181,6 +188,7 @@ __device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint
     // slow == 1 inside the literal run (rem, tok) the unit begins in.  slow == 0: the window parser below.
     int slow = 1;
     uint32_t nq = 0;                                        // tokens queued in s_tq
+    uint32_t last_ntok = DEC_BPERM_MIN; (void)last_ntok;    // tokens the last parsed window held (dec_fill_lean picks its chain walk by it)
     if (rem == HB_IDX_AT_TOKEN) { rem = 0; slow = 0; }
     while (ok && !done) {
         if (slow) {
@@ -227,7 +235,7 @@ __device__ __forceinline__ void dec_unit(const DecCtx &c, const uint32_t u, uint
             stage(si);
         }
 #if DEC_LEAN
-        const bool stop = dec_fill_lean(s_in, (uint32_t)shw, staged, slen, si, nq, s_tq, lane);
+        const bool stop = dec_fill_lean(s_in, (uint32_t)shw, staged, slen, si, nq, s_tq, lane, last_ntok);
         bool rewound = false;
         ok = dec_drain<true>(s_in, shw, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
 #else

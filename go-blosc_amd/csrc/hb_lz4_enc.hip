@@ -549,7 +549,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 const unsigned long long sel = m_rle & ~(m_rle << 1);
                 n_runs = 64u;
                 if (runny) asm volatile("s_bcnt1_i32_b64 %0, %1" : "=s"(n_runs) : "s"(sel) : "scc");      // (volatile: keeps the test behind the first branch -- most steps leave there)
-                if ((!ENC_GATE_ADAPT || gate_left > 0) && n_runs <= (uint32_t)ENC_GATE_MAXRUNS && m_rle != 0ull) {
+                if (runny && (!ENC_GATE_ADAPT || gate_left > 0) && n_runs - 1u < (uint32_t)ENC_GATE_MAXRUNS) {     // (1 .. MAXRUNS runs: sel != 0 <=> m_rle != 0)
                     gate_left--;
 #if ENC_GATE_ADAPT && !defined(ENC_GATE_NOINS)
                     // (the byte in front of the first run lane starts the run: its five bytes are the run's byte, so is its key)
@@ -585,7 +585,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                     {   // every lane stores: the lanes that are not selected to the spare slot behind the queue (a v_cndmask on the mask itself where
                         // a predicated store costs three scalar instructions -- the step loop issues as many scalar as vector instructions)
                         uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = 1u;
-                        s_q[hb_lane_in(sel) ? (uint32_t)nq + rank : (uint32_t)QCAP] = e;
+                        s_q[hb_select_lane(sel, (uint32_t)nq + rank, (uint32_t)QCAP)] = e;
                     }
                     nq += __builtin_popcountll(sel);
                     anchor = mpj + mlj;
@@ -797,7 +797,7 @@ __device__ __forceinline__ void match_chunk(const uint8_t *s_data, const uint32_
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
                 {
                     uint2 e; e.x = (uint32_t)p | (ml << 16); e.y = (uint32_t)p - cand;
-                    s_q[hb_lane_in(sel) ? (uint32_t)nq + rank : (uint32_t)QCAP] = e;       // (the spare slot: see the run step)
+                    s_q[hb_select_lane(sel, (uint32_t)nq + rank, (uint32_t)QCAP)] = e;       // (the spare slot: see the run step)
                 }
                 nq += __builtin_popcountll(sel);
                 anchor = last_end;
