@@ -183,10 +183,25 @@ __global__ __launch_bounds__(256) void k_shuffle_generic_batch(const hb_filter_j
 // (2 KiB), no loop (launch shape: see the top of the file).  The window's two 16-byte halves reach their lane through LDS, so that
 // every global access of the wave is one contiguous KiB (a lane reading its own 32 bytes makes every instruction touch half of each
 // 128-byte line: 5.6 TB/s in the lab against 6.4 for this exchange); the last, partial workgroup takes the direct path.
+// The GATED launches (the memcpy fallback of a fused frame, the un-filter behind the serial decoder) nearly always find their gate shut:
+// a quarter of a million empty workgroups cost 55 us per launch (round 4: that was the 0.1 ms between the step's kernels), so they get a small
+// grid that strides over the tiles -- slower by a tenth when the gate is open, 2 us when it is shut.
+template <int TS, bool INVERSE>
+__global__ __launch_bounds__(64) void k_shuffle_vec_gated(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
+                                                          uint64_t ne, uint64_t ntiles, const uint32_t *gate) {
+    __shared__ __attribute__((aligned(16))) uint32_t slab[TS][256];
+    if (*gate == 0) return;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        if (INVERSE) unshuffle_tile<TS>(dst, src, ne, t, slab, threadIdx.x);
+        else shuffle_tile<TS>(dst, src, ne, t, slab, threadIdx.x);
+        wave_sync();
+    }
+}
+
 template <bool INVERSE>
-__device__ __forceinline__ void bitshuffle4_tile(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, const uint64_t ngroups, u32x4 *slab) {
+__device__ __forceinline__ void bitshuffle4_tile(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, const uint64_t ngroups, u32x4 *slab, const uint64_t tile) {
     const int lane = threadIdx.x;
-    const uint64_t g0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t g0 = tile * 64;
     if (g0 + 64 <= ngroups) {
         const uint8_t *s = src + g0 * 32;
         const u32x4 v0 = ld16u_nt(s + lane * 16), v1 = ld16u_nt(s + 1024 + lane * 16);
@@ -216,8 +231,12 @@ template <bool INVERSE>
 __global__ __launch_bounds__(64) void k_bitshuffle4(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src,
                                                     uint64_t ngroups, const uint32_t *gate) {
     __shared__ __attribute__((aligned(16))) u32x4 slab[128];
-    if (gate && *gate == 0) return;
-    bitshuffle4_tile<INVERSE>(dst, src, ngroups, slab);
+    if (gate) {                                          // gated: a small grid strides over the tiles (see k_shuffle_vec_gated)
+        if (*gate == 0) return;
+        for (uint64_t t = blockIdx.x; t * 64 < ngroups; t += gridDim.x) { bitshuffle4_tile<INVERSE>(dst, src, ngroups, slab, t); wave_sync(); }
+        return;
+    }
+    bitshuffle4_tile<INVERSE>(dst, src, ngroups, slab, blockIdx.x);
 }
 template <bool INVERSE>
 __global__ __launch_bounds__(64) void k_bitshuffle4_batch(const hb_filter_job *__restrict__ jobs) {
@@ -226,7 +245,7 @@ __global__ __launch_bounds__(64) void k_bitshuffle4_batch(const hb_filter_job *_
     if (j.gate && *j.gate == 0) return;
     const uint64_t ng = j.n / 32;
     if ((uint64_t)blockIdx.x * 64 >= ng) return;
-    bitshuffle4_tile<INVERSE>(j.dst, j.src, ng, slab);
+    bitshuffle4_tile<INVERSE>(j.dst, j.src, ng, slab, blockIdx.x);
 }
 
 // any typesize: one thread per (group, byte position).  shuffle.go:184-200 / :261-277
@@ -281,6 +300,12 @@ static inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigne
 
 template <int TS>
 static void launch_shuffle_vec(bool inverse, uint8_t *dst, const uint8_t *src, uint64_t ne, uint64_t ntiles, const uint32_t *gate, hipStream_t s) {
+    if (gate) {
+        const unsigned g = (unsigned)(ntiles < 4096 ? ntiles : 4096);
+        if (!inverse) hipLaunchKernelGGL((k_shuffle_vec_gated<TS, false>), dim3(g), dim3(64), 0, s, dst, src, ne, ntiles, gate);
+        else hipLaunchKernelGGL((k_shuffle_vec_gated<TS, true>), dim3(g), dim3(64), 0, s, dst, src, ne, ntiles, gate);
+        return;
+    }
     const unsigned grid = (unsigned)ntiles;             // one tile per single-wave workgroup (n < 4 GiB: at most 2^21 tiles)
     if (!inverse) hipLaunchKernelGGL(k_shuffle_vec<TS>, dim3(grid), dim3(64), 0, s, dst, src, ne, ntiles, gate);
     else hipLaunchKernelGGL(k_unshuffle_vec<TS>, dim3(grid), dim3(64), 0, s, dst, src, ne, ntiles, gate);
@@ -330,7 +355,8 @@ static int launch_filter_impl(int op, uint8_t *dst, const uint8_t *src, size_t n
         const bool inv = (op == HB_OP_BITUNSHUFFLE);
         const uint64_t ng = ne / 8;
         if (ts == 4 && ng > 0) {
-            const unsigned grid = (unsigned)((ng + 63) / 64);
+            unsigned grid = (unsigned)((ng + 63) / 64);
+            if (gate && grid > 4096u) grid = 4096u;
             if (!inv) hipLaunchKernelGGL(k_bitshuffle4<false>, dim3(grid), dim3(64), 0, s, dst, src, ng, gate);
             else hipLaunchKernelGGL(k_bitshuffle4<true>, dim3(grid), dim3(64), 0, s, dst, src, ng, gate);
             if (ng * 32 < n)   // leftover elements + tail bytes only (g_begin = ng: no groups)
