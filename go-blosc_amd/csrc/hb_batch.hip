@@ -293,7 +293,9 @@ int hb_decompress_frames_batch_dev(int nframes, const hb_header *hdrs, const voi
             hb_prof_end(s);
         } else {
             hb_prof_begin(g.op == HB_OP_UNSHUFFLE ? "filter_unshuffle" : "filter_bitunshuffle", s);
-            rc = hb_launch_filter_batch(g.op, d_jobs + joff, (int)g.jobs.size(), g.max_n, g.ts, s);
+            bool all_gated = true;                                 // every job behind a gate (frames whose un-filter ran inside the indexed decoder): a few workgroups per job
+            for (const auto &j : g.jobs) if (!j.gate) { all_gated = false; break; }
+            rc = hb_launch_filter_batch(g.op, d_jobs + joff, (int)g.jobs.size(), g.max_n, g.ts, s, all_gated ? 1 : 0);
             hb_prof_end(s);
             if (rc) return rc;
         }

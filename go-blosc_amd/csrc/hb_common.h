@@ -139,4 +139,4 @@ int hb_launch_filter_gated(int op, uint8_t *d_dst, const uint8_t *d_src, size_t 
 bool hb_launch_shuffle_blocks(bool inverse, uint8_t *dst, const uint8_t *src, uint32_t nfull, uint32_t blocksize, int typesize, hipStream_t s);
 // the same filter on a batch of independent buffers (device array of jobs; gate as above, NULL = always)
 struct hb_filter_job { uint8_t *dst; const uint8_t *src; uint64_t n; const uint32_t *gate; };
-int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_t max_n, int typesize, hipStream_t s);
+int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_t max_n, int typesize, hipStream_t s, int gated = 0);

@@ -136,9 +136,11 @@ __global__ __launch_bounds__(64) void k_shuffle_vec_batch(const hb_filter_job *_
     const hb_filter_job j = jobs[blockIdx.y];
     if (j.gate && *j.gate == 0) return;
     const uint64_t ne = j.n / TS;
-    if (blockIdx.x >= ne / TILE_ELEMS) return;
-    if (INVERSE) unshuffle_tile<TS>(j.dst, j.src, ne, blockIdx.x, slab, threadIdx.x);
-    else shuffle_tile<TS>(j.dst, j.src, ne, blockIdx.x, slab, threadIdx.x);
+    for (uint64_t t = blockIdx.x; t < ne / TILE_ELEMS; t += gridDim.x) {      // (one round unless the launch is a gated one: a few workgroups per job then)
+        if (INVERSE) unshuffle_tile<TS>(j.dst, j.src, ne, t, slab, threadIdx.x);
+        else shuffle_tile<TS>(j.dst, j.src, ne, t, slab, threadIdx.x);
+        wave_sync();
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -244,8 +246,7 @@ __global__ __launch_bounds__(64) void k_bitshuffle4_batch(const hb_filter_job *_
     const hb_filter_job j = jobs[blockIdx.y];
     if (j.gate && *j.gate == 0) return;
     const uint64_t ng = j.n / 32;
-    if ((uint64_t)blockIdx.x * 64 >= ng) return;
-    bitshuffle4_tile<INVERSE>(j.dst, j.src, ng, slab, blockIdx.x);
+    for (uint64_t t = blockIdx.x; t * 64 < ng; t += gridDim.x) { bitshuffle4_tile<INVERSE>(j.dst, j.src, ng, slab, t); wave_sync(); }
 }
 
 // any typesize: one thread per (group, byte position).  shuffle.go:184-200 / :261-277
@@ -401,7 +402,8 @@ bool hb_launch_shuffle_blocks(bool inverse, uint8_t *dst, const uint8_t *src, ui
 // ---- batches (hb_*_frames_batch_dev): the same filter on `njobs` independent buffers in one or two launches.  d_jobs: device array;
 // max_n: the largest job (sizes the grid; jobs smaller than that leave their surplus workgroups at once).  Identity cases
 // (typesize <= 1, n < typesize: shuffle.go:17-19) are the caller's: it points the consumer at the source instead. ----
-int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_t max_n, int typesize, hipStream_t s) {
+// gated != 0: the jobs carry gates that are nearly always shut (the memcpy fallback of fused frames): a few workgroups per job stride over its tiles
+int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_t max_n, int typesize, hipStream_t s, int gated) {
     if (op < 0 || op > 3) return HB_ERR_BAD_ARG;
     if (njobs <= 0 || max_n == 0 || typesize <= 1) return HB_OK;
     const uint64_t ts = (uint64_t)typesize;
@@ -413,7 +415,7 @@ int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_
             const bool vec = ts == 2 || ts == 4 || ts == 8 || ts == 16;
             const uint64_t mt = max_n / ts / TILE_ELEMS;
             if (vec && mt) {
-                const dim3 g((unsigned)mt, ny);
+                const dim3 g((unsigned)(gated && mt > 4 ? 4 : mt), ny);
                 switch (ts) {
                 case 2: if (inv) hipLaunchKernelGGL((k_shuffle_vec_batch<2, true>), g, dim3(64), 0, s, jb); else hipLaunchKernelGGL((k_shuffle_vec_batch<2, false>), g, dim3(64), 0, s, jb); break;
                 case 4: if (inv) hipLaunchKernelGGL((k_shuffle_vec_batch<4, true>), g, dim3(64), 0, s, jb); else hipLaunchKernelGGL((k_shuffle_vec_batch<4, false>), g, dim3(64), 0, s, jb); break;
@@ -427,7 +429,8 @@ int hb_launch_filter_batch(int op, const hb_filter_job *d_jobs, int njobs, size_
         } else {
             const bool vec = ts == 4;
             if (vec && max_n / 32) {
-                const dim3 g((unsigned)((max_n / 32 + 63) / 64), ny);
+                const uint64_t gx = (max_n / 32 + 63) / 64;
+                const dim3 g((unsigned)(gated && gx > 4 ? 4 : gx), ny);
                 if (inv) hipLaunchKernelGGL(k_bitshuffle4_batch<true>, g, dim3(64), 0, s, jb); else hipLaunchKernelGGL(k_bitshuffle4_batch<false>, g, dim3(64), 0, s, jb);
             }
             const uint64_t items = vec ? 64 : max_n;

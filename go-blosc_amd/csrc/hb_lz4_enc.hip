@@ -1691,7 +1691,7 @@ int hb_launch_lz4_encode_batch(int nframes, const hb_batch_frame *fr, int codec,
                        (uint8_t *)nullptr, fi, (hb_result *)nullptr, has_index, (const BatchFrame *)d_bf);
     hb_prof_end(s);
     if (fused || fused_bits) {                                       // memcpy frames of a fused batch: the payload is filtered in place, frames that compressed leave at once
-        const int rc = hb_launch_filter_batch(fused_bits ? HB_OP_BITSHUFFLE : HB_OP_SHUFFLE, d_jobs + nframes, nframes, max_n, typesize, s);
+        const int rc = hb_launch_filter_batch(fused_bits ? HB_OP_BITSHUFFLE : HB_OP_SHUFFLE, d_jobs + nframes, nframes, max_n, typesize, s, 1);
         if (rc) return rc;
     }
     hb_prof_begin("k_stitch", s);
