@@ -74,6 +74,7 @@ static inline RgLayout rg_layout(size_t n_out) {
 // Queue entry: { tokpos | nbl << 16, lit | mlen << 16 }, positions relative to the window; literal bytes start at tokpos + 1 + nbl.
 __device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
     bool stop = false;
+    uint32_t last_ntok = DEC_BPERM_MIN;                   // (tokens of the previous window: picks the way the chain is followed; a call starts with the doubling)
     while (nq < 64u && !stop) {
         if (si == lim) { stop = true; break; }
         const uint32_t base = si, p = base + (uint32_t)lane;
@@ -126,9 +127,40 @@ __device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, 
         const unsigned long long cmask = hb_ballot(cplx);
         unsigned long long tmask = 0;
         uint32_t cur;
+        const uint32_t nrel = cplx ? 64u : nxt - base;
+        const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
+#if DEC_BPERM_WALK
+        if (last_ntok >= DEC_BPERM_MIN) {
+            // the chain of a token-dense window by pointer doubling, as dec_fill_lean follows it (hb_dec_common.h): lane k ends up holding the k-th
+            // token's lane and fetches that lane's entry -- the queue is written compacted, no scalar walk, no rank computation
+            const uint32_t s1 = succ;
+            const uint32_t s2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s1 << 2), (int)s1);
+            const uint32_t s4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s2 << 2), (int)s2);
+            const uint32_t s8 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s4 << 2), (int)s4);
+            const uint32_t s16 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s8 << 2), (int)s8);
+            uint32_t c = 0;
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s1); c = (lane & 1) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s2); c = (lane & 2) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s4); c = (lane & 4) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s8); c = (lane & 8) ? y : c; }
+            { const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)s16); c = (lane & 16) ? y : c; }
+            const uint32_t left = wave_shr1(c, 0xFFFFFFFFu);
+            const unsigned long long distinct = hb_ballot(c != left) | 0xFFFFFFFF00000000ull;
+            uint32_t ntok = (uint32_t)__builtin_ctzll(~distinct | (1ull << 32));
+            const uint32_t lastj = __builtin_amdgcn_readlane(c, (int)ntok - 1);
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            if ((cmask >> lastj) & 1ull) { ntok--; cur = base + lastj; stop = true; }
+            uint2 e;
+            e.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)(p | (nbl << 16)));
+            e.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)(lit | (mlen << 16)));
+            s_tq[(uint32_t)lane < ntok ? nq + (uint32_t)lane : (uint32_t)(DTQ - 1)] = e;
+            nq += ntok;
+            si = cur;
+            last_ntok = ntok;
+            continue;
+        }
+#endif
         {
-            const uint32_t nrel = cplx ? 64u : nxt - base;
-            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
             uint32_t j = 0, lastj;
             for (;;) {
                 asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
@@ -148,7 +180,8 @@ __device__ __forceinline__ bool rg_fill(const uint8_t *s_in, const uint32_t sh, 
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
         if ((tmask >> lane) & 1ull) { uint2 e; e.x = p | (nbl << 16); e.y = lit | (mlen << 16); s_tq[nq + rank] = e; }
-        nq += (uint32_t)__builtin_popcountll(tmask);
+        last_ntok = (uint32_t)__builtin_popcountll(tmask);
+        nq += last_ntok;
         si = cur;
     }
     return stop;
