@@ -476,7 +476,8 @@ int hb_decompress_frame_dev_hdr(const hb_header *hdr, const void *d_frame, size_
     // byte un-shuffle: fused into the indexed decoder (byte-strided stores) when the frame is whole planes of whole chunks
     // (typesize 8: every 128-byte line would be completed by 8 different waves -- measured 0.2 ms per GiB SLOWER than the
     // separate pass, while typesize 2 and 4 win 0.2 ms)
-    const bool fused_ush = unf == HB_OP_UNSHUFFLE && ts <= 4 && (h.nbytes % (uint32_t)ts) == 0 &&
+    static const int ush_max = [] { const char *e = getenv("HIPBLOSC_DEBUG_FUSED_UNSHUFFLE_MAX_TS"); return e && *e ? atoi(e) : 4; }();   // A/B (lab): 8 = typesize 8 fused too
+    const bool fused_ush = unf == HB_OP_UNSHUFFLE && ts <= ush_max && (ts == 2 || ts == 4 || ts == 8) && (h.nbytes % (uint32_t)ts) == 0 &&
                            ((h.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && !(h.flags & HB_FLAG_MEMCPY) && !g_no_dec_fusion && !snappy && has_index;
     uint8_t *target = (unf >= 0 && !fused_bun && !fused_ush) ? staged : (uint8_t *)d_dst;
     const uint8_t *payload = (const uint8_t *)d_frame + HB_HEADER_SIZE;

@@ -100,8 +100,9 @@ __global__ void k_bt_gather_headers(const uint8_t *const *__restrict__ frames, c
     if (i < n) { u32x4 z; z.x = z.y = z.z = z.w = 0; out[i] = valid[i] ? ld16u(frames[i]) : z; }
 }
 
-struct DecBatchLayout { size_t frames, plans, jobs, unit_frame, staged, total; };
-DecBatchLayout dec_batch_layout(int nframes, size_t total_units, size_t staged_bytes) {
+struct DecBatchLayout { size_t frames, plans, jobs, unit_frame, staged, rgjobs, rgwork, rgidx, total; };
+// rg_bytes / rgi_bytes: scratch / rebuilt index of the frames that come without a restart index and get one from the token discovery (hb_lz4_region.hip)
+DecBatchLayout dec_batch_layout(int nframes, size_t total_units, size_t staged_bytes, size_t rg_bytes, size_t rgi_bytes) {
     DecBatchLayout L{};
     size_t o = 0;
     auto take = [&](size_t b) { size_t at = o; o += al256(b); return at; };
@@ -110,6 +111,9 @@ DecBatchLayout dec_batch_layout(int nframes, size_t total_units, size_t staged_b
     L.jobs = take((size_t)nframes * sizeof(hb_filter_job));
     L.unit_frame = take(total_units * 4 + 64);
     L.staged = take(staged_bytes + 256);
+    L.rgjobs = take((size_t)nframes * sizeof(RgJob));
+    L.rgwork = take(rg_bytes + 256);
+    L.rgidx = take(rgi_bytes + 256);
     L.total = o;
     return L;
 }
@@ -172,12 +176,17 @@ int hb_frames_batch_headers_dev(int nframes, const void *const *d_frame, const s
 
 size_t hb_decompress_frames_batch_workspace(int nframes, const hb_header *hdrs) {
     if (nframes <= 0 || !hdrs) return 256;
-    size_t units = 0, staged = 0;
+    size_t units = 0, staged = 0, rg = 0, rgi = 0;
     for (int k = 0; k < nframes; k++) {
         units = (units + 31) / 32 * 32 + ((size_t)hdrs[k].nbytes + HB_CHUNK - 1) / HB_CHUNK;
         staged += al256((size_t)hdrs[k].nbytes + 64);
+        // (whether a frame brings its index is not in the header: room for every LZ4 frame's discovery)
+        if (!(hdrs[k].flags & HB_FLAG_MEMCPY) && hdrs[k].cbytes >= HB_HEADER_SIZE && hb_lz4_region_batch_wanted((size_t)hdrs[k].cbytes - HB_HEADER_SIZE, hdrs[k].nbytes)) {
+            rg += rg_batch_layout((size_t)hdrs[k].cbytes - HB_HEADER_SIZE).total;
+            rgi += al256(hb_lz4_index_bound(hdrs[k].nbytes));
+        }
     }
-    return dec_batch_layout(nframes, units + 32, staged).total;
+    return dec_batch_layout(nframes, units + 32, staged, rg, rgi).total;
 }
 
 // Per-frame outcome in d_results[k] (as hb_decompress_frame_dev reports it); frames whose header the host can already refuse get their
@@ -195,7 +204,8 @@ int hb_decompress_frames_batch_dev(int nframes, const hb_header *hdrs, const voi
     // frames the host refuses (blosc.go:385-390, :403-407; short destination) keep their place in the arrays as presets
     std::vector<DecBatchFrame> h((size_t)nframes);
     std::vector<int> unf((size_t)nframes, -1), tsv((size_t)nframes, 1);
-    size_t staged_total = 0;
+    size_t staged_total = 0, rg_total = 0, rgi_total = 0, rg_stream = 0;
+    std::vector<size_t> rg_off((size_t)nframes, (size_t)-1), rgi_off((size_t)nframes, 0);      // frames whose index is rebuilt on the device: offsets of their scratch / index
     for (int k = 0; k < nframes; k++) {
         const hb_header &hd = hdrs[k];
         DecBatchFrame &f = h[(size_t)k];
@@ -227,14 +237,41 @@ int hb_decompress_frames_batch_dev(int nframes, const hb_header *hdrs, const voi
         const size_t ioff = ((size_t)hd.cbytes + 7) & ~(size_t)7;
         const bool stored_index = n[k] > ioff + 32;
         if (stored_index) { f.index = (const uint8_t *)d_frame[k] + ioff; f.index_bytes = n[k] - ioff; f.nunits = (uint32_t)(((size_t)hd.nbytes + HB_CHUNK - 1) / HB_CHUNK); }
-        f.bun4 = (u == HB_OP_BITUNSHUFFLE && ts == 4 && (hd.nbytes % 32u) == 0 && ((uintptr_t)d_dst[k] & 15u) == 0 && stored_index) ? 1 : 0;
-        f.ush = (u == HB_OP_UNSHUFFLE && ts <= 4 && (hd.nbytes % (uint32_t)ts) == 0 && ((hd.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && stored_index) ? ts : 0;
+        // no index behind NBytesComp (the default frame shape, blosc.go:369-371): the token discovery rebuilds it for all such frames of the batch
+        // in one set of launches (hb_lz4_region.hip `_b` kernels); it is trusted no more than a stored one, and a frame whose chain does not check
+        // out (or that was not written chunk-locally) is left to the stream decoder below, as before
+        const bool rebuilt = !stored_index && hb_lz4_region_batch_wanted((size_t)f.n_src, hd.nbytes);
+        if (rebuilt) {
+            rg_off[(size_t)k] = rg_total; rg_total += rg_batch_layout((size_t)f.n_src).total;      // (sized for the smallest regions; the job may use fewer, longer ones)
+            rg_stream += (size_t)f.n_src;
+            rgi_off[(size_t)k] = rgi_total; rgi_total += al256(hb_lz4_index_bound(hd.nbytes));
+            f.nunits = (uint32_t)(((size_t)hd.nbytes + HB_CHUNK - 1) / HB_CHUNK);
+        }
+        const bool have_index = stored_index || rebuilt;
+        f.bun4 = (u == HB_OP_BITUNSHUFFLE && ts == 4 && (hd.nbytes % 32u) == 0 && ((uintptr_t)d_dst[k] & 15u) == 0 && have_index) ? 1 : 0;
+        f.ush = (u == HB_OP_UNSHUFFLE && ts <= 4 && (hd.nbytes % (uint32_t)ts) == 0 && ((hd.nbytes / (uint32_t)ts) % HB_CHUNK) == 0 && have_index) ? ts : 0;
         f.post_needed = (u >= 0) ? 1 : 0;
     }
     std::vector<uint32_t> unit0((size_t)nframes);
     const size_t total_units = hb_lz4_dec_batch_units(nframes, h.data(), unit0.data());
-    const DecBatchLayout L = dec_batch_layout(nframes, total_units, staged_total);
+    const DecBatchLayout L = dec_batch_layout(nframes, total_units, staged_total, rg_total, rgi_total);
     if (L.total > work_bytes) return HB_ERR_SHORT_BUFFER;
+    // jobs of the token discovery: scratch and index of frame k at rgwork + rg_off[k]
+    std::vector<RgJob> rgj;
+    uint32_t rg_maxreg = 0;
+    // region size of the batch: about 16384 regions in all (what one large frame gets), never below the one-frame path's 4 KiB, at most 64 KiB
+    const uint64_t rs_min = std::min<uint64_t>(65536, std::max<uint64_t>(4096, rg_stream / 16384));
+    for (int k = 0; k < nframes; k++) {
+        if (rg_off[(size_t)k] == (size_t)-1) continue;
+        DecBatchFrame &f = h[(size_t)k];
+        uint8_t *base = w + L.rgwork + rg_off[(size_t)k];
+        uint8_t *idx = w + L.rgidx + rgi_off[(size_t)k];
+        RgJob j;
+        hb_lz4_region_batch_job(base, idx, f.src, (size_t)f.n_src, (size_t)f.nbytes, &j, rs_min);
+        rg_maxreg = std::max(rg_maxreg, j.nreg);
+        rgj.push_back(j);
+        f.index = idx; f.index_bytes = hb_lz4_index_bound((size_t)f.nbytes);
+    }
     DecBatchFrame *d_bf = (DecBatchFrame *)(w + L.frames);
     DecPlan *d_plans = (DecPlan *)(w + L.plans);
     hb_filter_job *d_jobs = (hb_filter_job *)(w + L.jobs);
@@ -272,7 +309,15 @@ int hb_decompress_frames_batch_dev(int nframes, const hb_header *hdrs, const voi
         add_job(u, ts, hb_filter_job{final_dst, st, (uint64_t)hd.nbytes, fused ? &(d_plans + k)->post : nullptr});
     }
     HB_HIP_TRY(hipMemcpyAsync(d_bf, h.data(), h.size() * sizeof(DecBatchFrame), hipMemcpyHostToDevice, s));
-    int rc = hb_launch_lz4_decode_batch_indexed(nframes, d_bf, d_unit_frame, (uint32_t)total_units, max_ush, s);
+    int rc;
+    if (!rgj.empty()) {
+        RgJob *d_rgj = (RgJob *)(w + L.rgjobs);
+        HB_HIP_TRY(hipMemcpyAsync(d_rgj, rgj.data(), rgj.size() * sizeof(RgJob), hipMemcpyHostToDevice, s));
+        HB_HIP_TRY(hipMemsetAsync(w + L.rgidx, 0, rgi_total, s));       // (the indexes start zeroed: a build that fails leaves a header k_bt_dec_plan rejects)
+        rc = hb_launch_lz4_region_index_batch(d_rgj, (int)rgj.size(), rg_maxreg, s);
+        if (rc) return rc;
+    }
+    rc = hb_launch_lz4_decode_batch_indexed(nframes, d_bf, d_unit_frame, (uint32_t)total_units, max_ush, s);
     if (rc) return rc;
     hb_prof_begin("k_bt_dec_streams", s);
     hipLaunchKernelGGL(k_bt_dec_streams, dim3((unsigned)nframes), dim3(64), 0, s, (const DecBatchFrame *)d_bf);

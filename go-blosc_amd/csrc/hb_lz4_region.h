@@ -66,6 +66,44 @@ static inline RgLayout rg_layout(size_t n_out) {
     return L;
 }
 
+static inline void rg_regions(size_t n, uint64_t *rs_out, uint32_t *nreg_out);
+// ---- batches (hb_decompress_frames_batch_dev): the same kernels over MANY blocks in one set of launches.  Every kernel body takes its block
+// index and grid size as arguments; the `_b` launch reads its block's arguments from a job record (blockIdx.y = job) -- nothing else differs,
+// so a frame's index comes out exactly as the one-frame path builds it.  Blocks of a batch have at most RGB_MAXR regions (k_rg_settle keeps
+// entry + exit of every region in LDS: 128 KiB for the one-frame path's 16384 regions, 8 KiB here).
+#define RGB_MAXR 1024u
+struct RgJob {
+    const uint8_t *src; uint64_t n_src, cap;
+    RgPlan *plan; RgRegion *reg; uint2 *traces; uint32_t *pmax; uint2 *tok; uint8_t *idx;
+    uint32_t tokcap, nreg, rs, pad;
+};
+
+struct RgBatchLayout { size_t plan, reg, pmax, trace, tok, total; };
+// scratch of one job: sized by the block's own stream length (its regions), not by what a block of its decoded size could have
+// regions of a block inside a batch: at least rs_min bytes each (a batch of a thousand frames has parallelism to spare: fewer, longer regions cost
+// less start-up -- every region's parse begins with a guess and a stretch of tokens until it falls onto the chain)
+static inline void rg_regions_min(size_t n, uint64_t rs_min, uint64_t *rs_out, uint32_t *nreg_out) {
+    rg_regions(n, rs_out, nreg_out);
+    if (*rs_out < rs_min) { *rs_out = (rs_min + 15) & ~(uint64_t)15; *nreg_out = (uint32_t)((n + *rs_out - 1) / *rs_out); }
+}
+static inline RgBatchLayout rg_batch_layout(size_t n_src, uint64_t rs_min = 0) {
+    RgBatchLayout L; size_t o = 0;
+    auto take = [&](size_t b) { size_t at = o; o += (b + 255) & ~(size_t)255; return at; };
+    uint64_t rs; uint32_t nreg;
+    rg_regions_min(n_src, rs_min, &rs, &nreg);
+    L.plan = take(sizeof(RgPlan));
+    L.reg = take((size_t)(nreg + 1) * sizeof(RgRegion));
+    L.pmax = take((size_t)RGB_MAXR * 4);                     // (k_rg_index_tok clears done[r] for every workgroup of the launch: the batch's largest region count)
+    L.trace = take((size_t)nreg * RG_TRACE * sizeof(uint2));
+    L.tok = take((size_t)nreg * rg_tokcap(rs) * sizeof(uint2));
+    L.total = o;
+    return L;
+}
+bool hb_lz4_region_batch_wanted(size_t n_src, size_t cap);
+size_t hb_lz4_region_batch_bytes(size_t n_src, size_t cap);
+void hb_lz4_region_batch_job(uint8_t *w, uint8_t *idx, const uint8_t *src, size_t n_src, size_t cap, RgJob *j, uint64_t rs_min = 0);
+int hb_launch_lz4_region_index_batch(const RgJob *d_jobs, int njobs, uint32_t max_nreg, hipStream_t s);
+
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
 // Window-parallel token parser for the passes that copy nothing.  Like dec_fill (hb_dec_common.h), but every lane also sums

@@ -39,8 +39,9 @@ bool hb_lz4_region_wanted(const hb_dec_args &a) {
     return !a.index && !a.memcpy_payload && hb_indexless_parallel(a.n, a.cap) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull && a.n <= a.cap + a.cap / 255 + 16;
 }
 
-__global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void k_rg_init_body(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
+    const uint32_t r = bx_ * blockDim.x + threadIdx.x;
     if (r == 0) {
         plan->pad[1] = 0; plan->pad[2] = 0;
         plan->ok = 0; plan->fail = 0; plan->nreg = nreg; plan->rs = rs; plan->total = 0;
@@ -53,6 +54,8 @@ __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t r
     R.needfull = 1; R.pad0 = R.b; R.opos = 0; R.pad1[0] = RG_INVALID; R.pad1[1] = R.pad1[2] = R.pad1[3] = 0;
     reg[r] = R;
 }
+__global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) { k_rg_init_body(plan, reg, nreg, rs, blockIdx.x, gridDim.x); }
+__global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_init_body(j.plan, j.reg, j.nreg, j.rs, blockIdx.x, gridDim.x); }
 
 // ---- (1a) parse a region from its entry to the first token at / after the next region's start; no copies ----
 // parses region r from its believed first token (reg[r].entry) to the first token at / after the next region's start; one wavefront.
@@ -297,14 +300,14 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
     }
 }
 
-__global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first,
-                                                 uint2 *tok, uint32_t tokcap) {
+__device__ __forceinline__ void k_rg_parse_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first, uint2 *tok, uint32_t tokcap, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     const int lane = threadIdx.x;
     const uint32_t nreg = plan->nreg;
     if (!first && plan->pad[1] == 0u) return;                            // no region asked for a re-parse
-    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+    for (uint32_t r = bx_; r < nreg; r += gx_) {
         if (!RFL(reg[r].needfull)) continue;
 #ifdef RG_DEBUG_TIMES
         const uint64_t t0 = wall_clock64();
@@ -317,6 +320,8 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
 #endif
     }
 }
+__global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first, uint2 *tok, uint32_t tokcap) { k_rg_parse_body(src, n_src, plan, reg, traces, first, tok, tokcap, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void k_rg_parse_b(const RgJob *__restrict__ jobs, int first) { const RgJob j = jobs[blockIdx.y]; k_rg_parse_body(j.src, j.n_src, j.plan, j.reg, j.traces, first, j.tok, j.tokcap, blockIdx.x, gridDim.x); }
 
 // ---- (1b) settle the chain.  Belief of every region about its first token: the furthest position any predecessor's parse reaches (an
 // exclusive prefix maximum of the exits).  On the true chain exits are monotone, so this is the predecessor's exit; a token that
@@ -329,11 +334,12 @@ __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src
 // true chain by themselves (periodic data: stray and true chains run side by side), so that every region has to wait for its
 // predecessor's exit and be parsed from there.  Launch pairs would cost more than the hops: this kernel parses the regions that
 // ask for it itself (RG_FPARSERS wavefronts) and goes on, until nothing moves or RG_MAXHOPS.
-template <bool FINISH>
-__global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces) {
+template <bool FINISH, uint32_t MAXR>
+__device__ __forceinline__ void k_rg_settle_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     // (LDS: entry + exit of every region, one bit per region for "waits for a full parse"; output lengths stay in global memory --
     // they are written a few times per launch, read never)
-    __shared__ uint32_t s_entry[RG_MAXREG], s_exit[RG_MAXREG], s_needb[RG_MAXREG / 32];
+    __shared__ uint32_t s_entry[MAXR], s_exit[MAXR], s_needb[MAXR / 32];
     __shared__ uint32_t s_pm[1024];
     __shared__ uint32_t s_changed, s_pend, s_nlist;
     __shared__ __attribute__((aligned(16))) uint8_t s_pwin[FINISH ? RG_FPARSERS : 1][FINISH ? RG_PWIN + 128 : 16];
@@ -342,10 +348,10 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
     const int t = threadIdx.x;
     const uint32_t nreg = plan->nreg, bsh = plan->pad[0], rs = plan->rs;
     if (plan->pad[2]) return;                                           // an earlier launch came to a standstill with nothing pending
-    constexpr uint32_t PER = RG_MAXREG / 1024;
+    constexpr uint32_t PER = MAXR / 1024;
     auto need = [&](uint32_t r) __attribute__((always_inline)) -> bool { return (s_needb[r >> 5] >> (r & 31u)) & 1u; };
     auto set_need = [&](uint32_t r, bool v) __attribute__((always_inline)) { if (v) atomicOr(&s_needb[r >> 5], 1u << (r & 31u)); else atomicAnd(&s_needb[r >> 5], ~(1u << (r & 31u))); };
-    for (uint32_t k = (uint32_t)t; k < RG_MAXREG / 32; k += 1024u) s_needb[k] = 0u;
+    for (uint32_t k = (uint32_t)t; k < MAXR / 32; k += 1024u) s_needb[k] = 0u;
     if (t == 0) { s_changed = 0; s_pend = 0; s_nlist = 0; }
     __syncthreads();
     for (uint32_t k = 0; k < PER; k++) {
@@ -455,9 +461,14 @@ __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ 
     }
     if (t == 0) { plan->pad[1] = s_pend; if (!s_pend && !capped) plan->pad[2] = 1; }   // parses pending: the next k_rg_parse has work; else: settled
 }
+template <bool FINISH>
+__global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces) { k_rg_settle_body<FINISH, RG_MAXREG>(src, n_src, plan, reg, traces, blockIdx.x, gridDim.x); }
+template <bool FINISH>
+__global__ __launch_bounds__(1024) void k_rg_settle_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_settle_body<FINISH, RGB_MAXR>(j.src, j.n_src, j.plan, j.reg, j.traces, blockIdx.x, gridDim.x); }
 
 // the first round of (1b) has nearly every region re-walk its head: one lane per region over the whole chip instead of one workgroup
-__global__ __launch_bounds__(1024) void k_rg_pmax(RgPlan *plan, const RgRegion *reg, uint32_t *pmax) {
+__device__ __forceinline__ void k_rg_pmax_body(RgPlan *plan, const RgRegion *reg, uint32_t *pmax, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     __shared__ uint32_t s[1024];
     const int t = threadIdx.x;
     const uint32_t nreg = plan->nreg;
@@ -485,10 +496,12 @@ __global__ __launch_bounds__(1024) void k_rg_pmax(RgPlan *plan, const RgRegion *
         run = max(run, mine[k]);
     }
 }
-__global__ __launch_bounds__(64) void k_rg_fix(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces,
-                                               const uint32_t *__restrict__ pmax) {
+__global__ __launch_bounds__(1024) void k_rg_pmax(RgPlan *plan, const RgRegion *reg, uint32_t *pmax) { k_rg_pmax_body(plan, reg, pmax, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(1024) void k_rg_pmax_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_pmax_body(j.plan, j.reg, j.pmax, blockIdx.x, gridDim.x); }
+__device__ __forceinline__ void k_rg_fix_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces, const uint32_t *__restrict__ pmax, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     const uint32_t nreg = plan->nreg, bsh = plan->pad[0];
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = bx_ * blockDim.x + threadIdx.x;
     if (r == 0 || r >= nreg) return;
     RgRegion *R = reg + r;
     const uint32_t a = pmax[r], rb = R->b;
@@ -526,9 +539,12 @@ __global__ __launch_bounds__(64) void k_rg_fix(const uint8_t *__restrict__ src, 
     }
     R->exit = RG_INVALID; R->needfull = 1; plan->pad[1] = 1;            // k_rg_parse takes it from `entry`
 }
+__global__ __launch_bounds__(64) void k_rg_fix(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces, const uint32_t *__restrict__ pmax) { k_rg_fix_body(src, n_src, plan, reg, traces, pmax, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void k_rg_fix_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_fix_body(j.src, j.n_src, j.plan, j.reg, j.traces, j.pmax, blockIdx.x, gridDim.x); }
 
 // ---- (1c) verify the chain, give every region its output position ----
-__global__ __launch_bounds__(1024) void k_rg_scan(RgPlan *plan, RgRegion *reg, uint64_t n_src, uint64_t cap) {
+__device__ __forceinline__ void k_rg_scan_body(RgPlan *plan, RgRegion *reg, uint64_t n_src, uint64_t cap, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     __shared__ uint64_t s[1024];
     __shared__ uint32_t bad;
     const int t = threadIdx.x;
@@ -571,6 +587,8 @@ __global__ __launch_bounds__(1024) void k_rg_scan(RgPlan *plan, RgRegion *reg, u
         if (bad || total > cap || total > 0xFFFFFFF0ull) plan->fail = 1; else plan->ok = 1;
     }
 }
+__global__ __launch_bounds__(1024) void k_rg_scan(RgPlan *plan, RgRegion *reg, uint64_t n_src, uint64_t cap) { k_rg_scan_body(plan, reg, n_src, cap, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(1024) void k_rg_scan_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_scan_body(j.plan, j.reg, j.n_src, j.cap, blockIdx.x, gridDim.x); }
 
 // ---- (2) with the chain known, write the restart index the encoder would have appended (HBIX, hb_format.h): the decoder's state at
 // every HB_CHUNK bytes of output.  One wavefront per region walks its tokens (window-parallel parser again) with the region's
@@ -618,10 +636,10 @@ __device__ __forceinline__ bool rg_ext(const uint8_t *__restrict__ src, const ui
 // tokens 64 at a time; their output lengths add up backwards from the region's end to the output position of the first token on the chain (the
 // one at RgRegion.pad0), forwards to every token's own, and each lane writes the entries of the unit boundaries its sequence holds.  done[r] as
 // k_rg_index_fast leaves it (which then only takes the regions this kernel left at 0: no usable store, a token with 32-bit lengths).
-__global__ __launch_bounds__(64) void k_rg_index_tok(const uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint2 *__restrict__ tok, const uint32_t tokcap,
-                                                     uint8_t *__restrict__ index, uint32_t *__restrict__ done) {
+__device__ __forceinline__ void k_rg_index_tok_body(const uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint2 *__restrict__ tok, const uint32_t tokcap, uint8_t *__restrict__ index, uint32_t *__restrict__ done, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     const int lane = threadIdx.x;
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = bx_;
     if (lane == 0) done[r] = 0u;
     if (!plan->ok || __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || r >= plan->nreg) return;
     const uint64_t N = plan->total;
@@ -685,12 +703,14 @@ __global__ __launch_bounds__(64) void k_rg_index_tok(const uint64_t n_src, RgPla
     if (inmatch) { if (lane == 0) { done[r] = 6u; if (!__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicExch(&plan->fail, 1u); } return; }
     if (lane == 0) done[r] = pad0 > start ? pad0 : 0xFFFFFFFFu;        // the head [entry, pad0) is still to do (nothing, when the chain starts on the record)
 }
+__global__ __launch_bounds__(64) void k_rg_index_tok(const uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint2 *__restrict__ tok, const uint32_t tokcap, uint8_t *__restrict__ index, uint32_t *__restrict__ done) { k_rg_index_tok_body(n_src, plan, reg, tok, tokcap, index, done, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void k_rg_index_tok_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_index_tok_body(j.n_src, j.plan, j.reg, j.tok, j.tokcap, j.idx, j.pmax, blockIdx.x, gridDim.x); }
 
-__global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
-                                                      const uint2 *__restrict__ traces, uint8_t *__restrict__ index, uint32_t *__restrict__ done, int after_tok) {
+__device__ __forceinline__ void k_rg_index_fast_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint2 *__restrict__ traces, uint8_t *__restrict__ index, uint32_t *__restrict__ done, int after_tok, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     __shared__ uint2 s_tr[RG_BUCKETS + 1];
     const int lane = threadIdx.x;
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = bx_;
     if (after_tok) { if (r < plan->nreg && RFL(done[r]) != 0u) return; }                // k_rg_index_tok did this region (or gave the verdict)
     else if (lane == 0) done[r] = 0u;
     if (!plan->ok || __hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || r >= plan->nreg) return;
@@ -789,9 +809,11 @@ __global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict_
     if (hb_ballot(bad)) { if (lane == 0) done[r] = 6u; return; }
     if (lane == 0) done[r] = headend;                                   // the head [entry, first usable record) is still to do
 }
+__global__ __launch_bounds__(64) void k_rg_index_fast(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint2 *__restrict__ traces, uint8_t *__restrict__ index, uint32_t *__restrict__ done, int after_tok) { k_rg_index_fast_body(src, n_src, plan, reg, traces, index, done, after_tok, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void k_rg_index_fast_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_index_fast_body(j.src, j.n_src, j.plan, j.reg, j.traces, j.idx, j.pmax, 1, blockIdx.x, gridDim.x); }
 
-__global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg,
-                                                 const uint32_t *__restrict__ done, uint8_t *__restrict__ index) {
+__device__ __forceinline__ void k_rg_index_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint32_t *__restrict__ done, uint8_t *__restrict__ index, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     if (!plan->ok || plan->fail) return;
@@ -799,7 +821,7 @@ __global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src
     const uint32_t nreg = plan->nreg;
     const uint64_t N = plan->total;
     uint8_t *ents = index + HB_IDX_HDR_BYTES;
-    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+    for (uint32_t r = bx_; r < nreg; r += gx_) {
         if (__hip_atomic_load(&plan->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // somebody found a boundary inside a match
         const uint32_t start = RFL(reg[r].entry), exitp = RFL(reg[r].exit);
         if (RFL(reg[r].outlen) == 0u || start >= exitp) continue;
@@ -846,9 +868,12 @@ __global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src
 #endif
     }
 }
+__global__ __launch_bounds__(64) void k_rg_index(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, const RgRegion *__restrict__ reg, const uint32_t *__restrict__ done, uint8_t *__restrict__ index) { k_rg_index_body(src, n_src, plan, reg, done, index, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void k_rg_index_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_index_body(j.src, j.n_src, j.plan, j.reg, j.pmax, j.idx, blockIdx.x, gridDim.x); }
 
 // first entry, terminator and header (written last: a failed build leaves the zeroed header, which k_dec_plan rejects)
-__global__ void k_rg_index_head(RgPlan *plan, uint8_t *__restrict__ index, uint64_t n_src) {
+__device__ __forceinline__ void k_rg_index_head_body(RgPlan *plan, uint8_t *__restrict__ index, uint64_t n_src, const uint32_t bx_, const uint32_t gx_) {
+    (void)bx_; (void)gx_;
     if (!plan->ok || plan->fail) return;
     const uint64_t N = plan->total;
     const uint32_t nunits = (uint32_t)((N + HB_CHUNK - 1) / HB_CHUNK);
@@ -862,6 +887,8 @@ __global__ void k_rg_index_head(RgPlan *plan, uint8_t *__restrict__ index, uint6
     h[4] = (uint32_t)n_src; h[5] = (uint32_t)N; h[6] = 0;
     h[7] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4] ^ h[5];
 }
+__global__ void k_rg_index_head(RgPlan *plan, uint8_t *__restrict__ index, uint64_t n_src) { k_rg_index_head_body(plan, index, n_src, blockIdx.x, gridDim.x); }
+__global__ void k_rg_index_head_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_index_head_body(j.plan, j.idx, j.n_src, blockIdx.x, gridDim.x); }
 
 // Builds the restart index of an index-less block in the workspace; *index / *index_bytes then go to k_dec_plan / k_dec_indexed as if
 // the frame had carried them (an index that could not be built stays zeroed and is rejected there: serial decode).
@@ -916,5 +943,62 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     hb_prof_end(s);
     HB_HIP_TRY(hipGetLastError());
     *index = idx; *index_bytes = ib;
+    return HB_OK;
+}
+
+
+// ---- the index of MANY index-less blocks in one set of launches (hb_decompress_frames_batch_dev) ----
+// One job per block; a job's scratch is laid out by rg_batch_layout (plan, regions, pmax / done, traces, token store), its index goes to `idx`.
+// A block whose chain does not verify, or that was not written chunk-locally, ends with a zeroed index header: k_bt_dec_plan rejects it and the
+// stream decoder takes the frame, as before.
+bool hb_lz4_region_batch_wanted(size_t n_src, size_t cap) {
+    if (!hb_indexless_parallel(n_src, cap) || n_src >= 0xFFFFFFF0ull || cap >= 0xFFFFFFF0ull || n_src > cap + cap / 255 + 16) return false;
+    uint64_t rs; uint32_t nreg;
+    rg_regions(n_src, &rs, &nreg);
+    return nreg <= RGB_MAXR;
+}
+size_t hb_lz4_region_batch_bytes(size_t n_src, size_t cap) {
+    if (!hb_lz4_region_batch_wanted(n_src, cap)) return 0;
+    return rg_batch_layout(n_src).total + ((hb_lz4_index_bound(cap) + 255) & ~(size_t)255);
+}
+void hb_lz4_region_batch_job(uint8_t *w, uint8_t *idx, const uint8_t *src, size_t n_src, size_t cap, RgJob *j, uint64_t rs_min) {
+    const RgBatchLayout L = rg_batch_layout(n_src, rs_min);
+    uint64_t rs; uint32_t nreg;
+    rg_regions_min(n_src, rs_min, &rs, &nreg);
+    j->src = src; j->n_src = n_src; j->cap = cap;
+    j->plan = (RgPlan *)(w + L.plan); j->reg = (RgRegion *)(w + L.reg); j->pmax = (uint32_t *)(w + L.pmax);
+    j->traces = (uint2 *)(w + L.trace); j->tok = (uint2 *)(w + L.tok); j->idx = idx;
+    j->tokcap = rg_tokcap(rs); j->nreg = nreg; j->rs = (uint32_t)rs; j->pad = 0;
+}
+int hb_launch_lz4_region_index_batch(const RgJob *d_jobs, int njobs, uint32_t max_nreg, hipStream_t s) {
+    if (njobs <= 0) return HB_OK;
+    for (int j0 = 0; j0 < njobs; j0 += 65535) {                       // gridDim.y <= 65535
+        const unsigned ny = (unsigned)(njobs - j0 < 65535 ? njobs - j0 : 65535);
+        const RgJob *jb = d_jobs + j0;
+        hb_prof_begin("k_rg_parse", s);
+        hipLaunchKernelGGL(k_rg_init_b, dim3((max_nreg + 255) / 256, ny), dim3(256), 0, s, jb);
+        hipLaunchKernelGGL(k_rg_parse_b, dim3(max_nreg, ny), dim3(64), 0, s, jb, 1);
+        hb_prof_end(s);
+        hb_prof_begin("k_rg_fix", s);
+        hipLaunchKernelGGL(k_rg_pmax_b, dim3(1, ny), dim3(1024), 0, s, jb);
+        hipLaunchKernelGGL(k_rg_fix_b, dim3((max_nreg + 63) / 64, ny), dim3(64), 0, s, jb);
+        hipLaunchKernelGGL(k_rg_parse_b, dim3(max_nreg, ny), dim3(64), 0, s, jb, 0);
+        hb_prof_end(s);
+        hb_prof_begin("k_rg_settle", s);
+        for (int k = 0; k < RG_FIXROUNDS; k++) {
+            hipLaunchKernelGGL(k_rg_settle_b<false>, dim3(1, ny), dim3(1024), 0, s, jb);
+            hipLaunchKernelGGL(k_rg_parse_b, dim3(max_nreg < 64u ? max_nreg : 64u, ny), dim3(64), 0, s, jb, 0);
+        }
+        hipLaunchKernelGGL(k_rg_settle_b<true>, dim3(1, ny), dim3(1024), 0, s, jb);
+        hipLaunchKernelGGL(k_rg_scan_b, dim3(1, ny), dim3(1024), 0, s, jb);
+        hb_prof_end(s);
+        hb_prof_begin("k_rg_index", s);
+        hipLaunchKernelGGL(k_rg_index_tok_b, dim3(max_nreg, ny), dim3(64), 0, s, jb);
+        hipLaunchKernelGGL(k_rg_index_fast_b, dim3(max_nreg, ny), dim3(64), 0, s, jb);
+        hipLaunchKernelGGL(k_rg_index_b, dim3(max_nreg, ny), dim3(64), 0, s, jb);
+        hipLaunchKernelGGL(k_rg_index_head_b, dim3(1, ny), dim3(1), 0, s, jb);
+        hb_prof_end(s);
+    }
+    HB_HIP_TRY(hipGetLastError());
     return HB_OK;
 }

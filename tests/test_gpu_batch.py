@@ -97,6 +97,36 @@ def test_batch_decodes_what_others_wrote_and_reports_like_the_one_call_decoder(h
             assert got[i] == want, i
 
 
+def test_default_shape_frames_of_a_batch_get_their_index_rebuilt(hb, O):
+    # round 4: frames of a batch that end at NBytesComp (what Compress returns by default, blosc.go:369-371) and are large enough for the token discovery
+    # (>= 256 KiB of payload) get their restart index rebuilt for the whole batch in one set of launches (hb_lz4_region.hip `_b` kernels) and decode
+    # chunk-parallel; frames somebody else wrote (one block, 64 KiB window) and damaged frames fall through to the stream decoder / the authority and
+    # must report exactly what the one-call decoder reports
+    rng = np.random.default_rng(11)
+    n = 3 << 19                                                            # 1.5 MiB
+    xs = [O.synth(O.D_F32, n // 4, frame=1).tobytes(), O.synth(O.D_I32, n // 4).tobytes(), O.synth(O.D_F64, n // 8).tobytes(),
+          O.synth(O.D_RAND, n // 4).tobytes(), rng.integers(0, 7, n, dtype=np.uint8).tobytes(), O.synth(O.D_RAMP, n // 4).tobytes()]
+    cfg = [(hb.Shuffle1, 4), (hb.BitShuffle, 4), (hb.Shuffle1, 8), (hb.Shuffle1, 4), (hb.NoShuffle, 1), (hb.Shuffle1, 2)]
+    frames = [hb.Compress(x, hb.LZ4, 5, sh, ts, opts=0) for x, (sh, ts) in zip(xs, cfg)]
+    for f, x in zip(frames, xs):
+        assert len(f) == hb.GetInfo(f).NBytesComp                           # no trailer
+    foreign = O.compress_frame(np.frombuffer(xs[0], np.uint8), shuffle=1, typesize=4).tobytes()
+    bad = bytearray(frames[0]); bad[5000:5040] = bytes(b ^ 0x5A for b in bad[5000:5040])
+    trunc = bytearray(frames[1]); trunc[12:16] = (len(trunc) - 4000).to_bytes(4, "little")      # a shorter NBytesComp: the stream ends early
+    batch = frames + [foreign, bytes(bad), bytes(trunc[: len(trunc) - 4000])] + frames[::-1]
+    got = hb.DecompressBatch(batch)
+    for i, f in enumerate(batch):
+        try:
+            want = hb.Decompress(f)
+        except hb.BloscError as e:
+            want = type(e)
+        if isinstance(want, type):
+            assert isinstance(got[i], want), (i, got[i], want)
+        else:
+            assert got[i] == want, i
+    assert got[: len(xs)] == xs and got[len(xs)] == xs[0]
+
+
 def test_large_batch_of_the_reference_benchmark_frame(hb, O):
     # 512 x the 100 000-byte byte(i % 256) frame of blosc_test.go:363-371 + 512 x a float frame: every frame equal to the one-call frame
     a = bytes(i % 256 for i in range(100000))

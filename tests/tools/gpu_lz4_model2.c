@@ -44,6 +44,7 @@ int main(int argc, char **argv) {
     const int gate = argc > 4 ? atoi(argv[4]) : 0, minlen = argc > 5 ? atoi(argv[5]) : 4, W = argc > 6 ? atoi(argv[6]) : 64;
     const int flags = argc > 7 ? atoi(argv[7]) : 0, aux = argc > 8 ? atoi(argv[8]) : 7;
     const int chunk = 4096, accel = 64;
+    const int stride2 = getenv("STRIDE2") ? atoi(getenv("STRIDE2")) : 0;   /* 1: full steps probe every other position (model of a 128-byte step with one position per lane) */
     uint16_t *tab = malloc(sizeof(uint16_t) << g_hlog);
     uint64_t out = 0, nseq = 0, steps = 0, hitsteps = 0, gatesteps = 0, carry = 0, hitlanes = 0, longs = 0;
     uint64_t mlhist[6] = {0};   /* match length: 4-7, 8-11, 12-19, 20-63, 64-255, 256+ */
@@ -72,6 +73,7 @@ int main(int argc, char **argv) {
                     const uint32_t v = rd4(d + p);
                     const int rle = p >= 1 && d[p - 1] == d[p] && v == (v & 255u) * 0x01010101u;
                     if (rle) continue;
+                    if (stride2 && !gated && (l & 1)) continue;
                     if (gated && !(flags & 1)) {
                         /* bit2: a run step still inserts the first byte of every run it selects (the position in front of the first run lane) */
                         if (!(flags & 4)) continue;
@@ -82,6 +84,7 @@ int main(int argc, char **argv) {
             }
             int any = 0;
             for (int l = 0; l < W; l++) { const int p = pos + l; if (p > ms) continue;
+                if (stride2 && !gated && (l & 1)) continue;            /* STRIDE2: odd positions are neither probed nor run candidates */
                 const uint32_t v = rd4(d + p);
                 const int rle = p >= 1 && d[p - 1] == d[p] && v == (v & 255u) * 0x01010101u;
                 int c = -1;
