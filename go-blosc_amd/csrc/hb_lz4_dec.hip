@@ -356,11 +356,19 @@ __global__ __launch_bounds__(64) void k_bt_dec_plan(const DecBatchFrame *__restr
     const uint32_t f = blockIdx.x;
     const DecBatchFrame b = bf[f];
     const uint32_t next = f + 1 < nframes ? bf[f + 1].unit0 : total_units;
-    for (uint32_t u = threadIdx.x; u < next - b.unit0; u += 64) unit_frame[b.unit0 + u] = u < b.nunits ? f : 0xFFFFFFFFu;
+    __shared__ uint32_t s_mode;
     if (threadIdx.x == 0) {
         dec_plan_check(b.preset == 1 ? b.index : nullptr, b.index_bytes, b.n_src, (uint64_t)b.nbytes, b.plan, b.result);
         b.plan->pad[0] = 0; b.plan->pad[1] = 0;                      // (stream decoder's verdict and byte count, k_bt_dec_streams)
+        // an index that speaks of another geometry than the frame's header (fewer bytes, other units) is no index: the stream decides
+        if (b.plan->mode == DEC_INDEXED && (b.plan->nunits != b.nunits || b.plan->nbytes != b.nbytes)) b.plan->mode = DEC_SERIAL;
+        s_mode = b.plan->mode;
     }
+    __syncthreads();
+    // the units of a frame whose index did not check out belong to nobody: k_dec_indexed_batch then needs no look at the plan (one dependent memory
+    // round trip less in front of every unit)
+    const bool indexed = s_mode == DEC_INDEXED;
+    for (uint32_t u = threadIdx.x; u < next - b.unit0; u += 64) unit_frame[b.unit0 + u] = (u < b.nunits && indexed) ? f : 0xFFFFFFFFu;
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES))) void k_dec_indexed_batch(const DecBatchFrame *__restrict__ bf,
@@ -373,9 +381,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES)))
         const uint32_t fid = unit_frame[it];
         if (fid == 0xFFFFFFFFu) continue;
         const DecBatchFrame &f = bf[fid];
-        if (f.plan->mode != DEC_INDEXED) continue;
         DecCtx c; c.src = f.src; c.n_src = f.n_src; c.dst = f.dst; c.ent = f.index + HB_IDX_HDR_BYTES; c.plan = f.plan;
-        c.nbytes = f.plan->nbytes; c.nunits = f.plan->nunits; c.bun4 = f.bun4; c.ush = f.ush;
+        c.nbytes = f.nbytes; c.nunits = f.nunits; c.bun4 = f.bun4; c.ush = f.ush;       // (= the plan's: k_bt_dec_plan gave the units to this frame only then)
         uint32_t u = it - f.unit0;
         if (c.ush) {
             // fused un-shuffle: as in k_dec_indexed -- the `ush` units of an element block get workgroup ids equal mod 8 (a frame's
