@@ -57,6 +57,12 @@ __device__ __forceinline__ void k_rg_init_body(RgPlan *plan, RgRegion *reg, uint
 __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) { k_rg_init_body(plan, reg, nreg, rs, blockIdx.x, gridDim.x); }
 __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_init_body(j.plan, j.reg, j.nreg, j.rs, blockIdx.x, gridDim.x); }
 
+#ifndef RG_LEAN_PARSE
+#define RG_LEAN_PARSE 1
+#endif
+#ifndef RG_FAT_HOLD
+#define RG_FAT_HOLD 8u
+#endif
 // ---- (1a) parse a region from its entry to the first token at / after the next region's start; no copies ----
 // parses region r from its believed first token (reg[r].entry) to the first token at / after the next region's start; one wavefront.
 // first: nothing is on record yet.  s_win: RG_PWIN + 128 bytes, s_tq: DTQ entries, both this wave's own.
@@ -83,6 +89,8 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
         if (!mm) for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
         uint64_t si = start, wpos = 0, out = 0;
         uint32_t wlen = 0, wsh = 0, nq = 0, ntok = 0, exitp = RG_INVALID, lastbk = RG_INVALID;
+        uint32_t last_ntok = DEC_BPERM_MIN;                              // (dec_fill_lean: how the previous window's chain was followed)
+        uint32_t fat_hold = 0;                                           // windows the fat parser still has
         bool invalid = false, merged = false;
         uint32_t mpos = 0, mcum = 0, mc0 = 0;
         auto refill = [&](uint64_t at) __attribute__((always_inline)) {
@@ -189,11 +197,43 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             if (si >= bnext) { exitp = (uint32_t)si; break; }           // (si <= n_src always; bnext <= n_src)
             if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
             uint32_t rel = (uint32_t)(si - wpos);
-            const bool stop = rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
+            // Two window parsers.  LEAN (dec_fill_lean, hb_dec_common.h: the indexed decoder's): a lane only works out how long the sequence at its
+            // byte would be, taking a length extension for ONE byte; the queue gets the positions of the real tokens and their fields are parsed
+            // below, by lanes that all hold one.  FAT (rg_fill): every lane parses its "as if" token in full, extensions of up to 24 bytes included.
+            // Lean is the faster one per window (bit-shuffled integers: 0.82 against 1.39 ms per GiB) but loses the rest of a window at every
+            // token with a longer extension, and where the stream is made of those (a plane of runs: one 19-byte sequence per 4 KiB chunk) a region
+            // is a latency chain of window passes per token (measured with lean alone: 8.5 ms instead of 1.2 -- 40 such regions of 16 384 are
+            // the launch).  So a longer extension switches to the fat parser, which stays until RG_FAT_HOLD windows in a row met none.
+            const bool fat = !RG_LEAN_PARSE || fat_hold != 0u;
+            bool stop, refat = false;
+            if (fat) stop = rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
+            else stop = dec_fill_lean(s_win, wsh, wlen, wlen, rel, nq, s_tq, lane, last_ntok);
+            if (fat_hold) fat_hold--;
             bool done = false;
             while (nq > 0u) {                                           // account for the queued tokens, 64 at a time
-                const uint32_t cntb = nq < 64u ? nq : 64u;
-                const uint2 e = s_tq[lane];
+                uint32_t cntb = nq < 64u ? nq : 64u;
+                uint2 e;
+                if (!fat) {
+                    const uint32_t tp = (uint32_t)lane < cntb ? (uint32_t)((const uint16_t *)s_tq)[lane] : 0u;
+                    const uint32_t w = dec_read4(s_win, wsh + tp);
+                    const uint32_t t = w & 255u, b1 = (w >> 8) & 255u;
+                    const bool big = t >= 0xF0u;
+                    const uint32_t lit = big ? 15u + b1 : (t >> 4);
+                    const uint32_t x = dec_read4(s_win, wsh + tp + (big ? 2u : 1u) + lit);
+                    const uint32_t mb = (x >> 16) & 255u, mn = t & 15u;
+                    const uint32_t mlen = mn == 15u ? 19u + mb : 4u + mn;
+                    e.x = tp; e.y = lit | (mlen << 16);
+                    const unsigned long long xm = hb_ballot((uint32_t)lane < cntb && ((big && b1 == 255u) || (mn == 15u && mb == 255u)));
+                    if (xm) {                                           // what was queued behind that token is not on the chain: go on from it, fat
+                        const uint32_t jx = (uint32_t)__builtin_ctzll(xm);
+                        rel = (uint32_t)__builtin_amdgcn_readlane(tp, (int)jx);
+                        cntb = jx; nq = jx; refat = true; fat_hold = RG_FAT_HOLD;
+                        if (jx == 0u) break;
+                    }
+                } else {
+                    e = s_tq[lane];
+                    if (hb_ballot((uint32_t)lane < cntb && ((e.y & 0xFFFFu) >= 270u || (e.y >> 16) >= 274u))) fat_hold = RG_FAT_HOLD;
+                }
                 const uint32_t lit = e.y & 0xFFFFu, mlen = e.y >> 16;
                 const uint64_t ap = wpos + (e.x & 0xFFFFu);
                 const unsigned long long over = hb_ballot((uint32_t)lane < cntb && ap >= bnext);
@@ -226,11 +266,18 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
                 ntok += cnt;
                 if (over) { exitp = RFL(__builtin_amdgcn_readlane((uint32_t)ap, (int)__builtin_ctzll(over))); done = true; nq = 0; break; }
-                const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
-                nq -= cntb;
-                if ((uint32_t)lane < nq) s_tq[lane] = rest;
+                if (!fat) {
+                    const uint16_t rest = ((const uint16_t *)s_tq)[64 + lane < DTQ ? 64 + lane : 0];
+                    nq -= cntb;
+                    ((uint16_t *)s_tq)[lane] = rest;
+                } else {
+                    const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
+                    nq -= cntb;
+                    if ((uint32_t)lane < nq) s_tq[lane] = rest;
+                }
             }
             if (done) break;
+            if (refat) { si = wpos + rel; continue; }
             const bool moved = (wpos + rel) != si;
             si = wpos + rel;
             if (moved && !stop) continue;
@@ -281,6 +328,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             out += (uint64_t)ll + ml;
             ntok++;
             si = p;
+            if (ll >= 270u || ml >= 274u) fat_hold = RG_FAT_HOLD;
             if (out > 0xFFFFFFF0ull) { invalid = true; break; }
         }
         if (out > 0xFFFFFFF0ull) invalid = true;
