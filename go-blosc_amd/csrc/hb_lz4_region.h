@@ -106,6 +106,87 @@ int hb_launch_lz4_region_index_batch(const RgJob *d_jobs, int njobs, uint32_t ma
 
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
+// ---- the same discovery for Snappy blocks (hb_snappy.hip: blocks that come without a unit index, i.e. written by any other encoder) ----
+// The kernels that parse are templated on the codec: elements instead of sequences.  CODEC of rg_parse_region / k_rg_settle_body / k_rg_fix_body.
+enum { RG_LZ4 = 0, RG_SNAPPY = 1 };
+// one element, all values wave-uniform: `p[k]` = stream byte k of a buffer holding `avail` bytes from the element's tag.  false: the header runs off the buffer.
+struct SnElem { uint32_t kind, hdr; uint64_t lit; uint32_t mlen; uint64_t off; };
+__device__ __forceinline__ bool sn_parse_uniform(const uint8_t *p, uint64_t avail, SnElem &e) {
+    if (avail < 1) return false;
+    const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)p[0]);
+    e.kind = t & 3u; e.lit = 0; e.mlen = 0; e.off = 0; e.hdr = 1;
+    const uint32_t x = t >> 2;
+    auto byte = [&](uint32_t i) { return (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)p[i]); };
+    if (e.kind == 0u) {
+        if (x < 60u) e.lit = x + 1u;
+        else {
+            const uint32_t nb = x - 59u;                          // 1..4 length bytes
+            if (avail < 1u + nb) return false;
+            uint64_t v = 0;
+            for (uint32_t i = 0; i < nb; i++) v |= byte(1u + i) << (8u * i);
+            e.lit = v + 1u; e.hdr = 1u + nb;
+        }
+    } else if (e.kind == 1u) { if (avail < 2) return false; e.mlen = 4u + (x & 7u); e.off = ((uint64_t)(t >> 5) << 8) | byte(1); e.hdr = 2; }
+    else if (e.kind == 2u) { if (avail < 3) return false; e.mlen = 1u + x; e.off = byte(1) | (byte(2) << 8); e.hdr = 3; }
+    else { if (avail < 5) return false; e.mlen = 1u + x; e.off = byte(1) | (byte(2) << 8) | (byte(3) << 16) | (byte(4) << 24); e.hdr = 5; }
+    return true;
+}
+// Window-parallel element parser for the passes that copy nothing (rg_fill's counterpart): 64 lanes parse 64 stream bytes "as if an element started
+// at my byte", the chain is followed on the scalar side (Snappy windows hold up to 32 elements, but a parse is not the decoder's hot loop).
+// Queue entry: {position (window-relative), output bytes of the element}.  An element whose header does not lie inside the window, or a literal whose
+// length takes three or four bytes, ends the walk (-> sn_parse_uniform).  si may come back beyond lim: a literal's bytes need not be staged.
+__device__ __forceinline__ bool sn_rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si >= lim) { stop = true; break; }
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t w = dec_read4(s_in, sh + p);
+        const uint32_t t = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, kind = t & 3u, x = t >> 2;
+        bool cplx = p + 5u > lim;
+        uint32_t olen, hdr, lit = 0;
+        if (kind == 0u) {
+            hdr = 1u; lit = x + 1u;
+            if (x == 60u) { lit = b1 + 1u; hdr = 2u; }
+            else if (x == 61u) { lit = (b1 | (b2 << 8)) + 1u; hdr = 3u; }
+            else if (x > 61u) cplx = true;
+            olen = lit;
+        } else if (kind == 1u) { olen = 4u + (x & 7u); hdr = 2u; }
+        else { olen = 1u + x; hdr = kind == 2u ? 3u : 5u; }
+        const uint32_t nrel = cplx ? 64u : (uint32_t)lane + hdr + lit;
+        const unsigned long long cmask = hb_ballot(cplx);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
+            uint32_t j = 0, lastj;
+            for (;;) {
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            const unsigned long long cm = tmask & cmask;
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) { uint2 e; e.x = p; e.y = olen; s_tq[nq + rank] = e; }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+        if (si > lim) break;                                     // (the rest of a literal lies behind the window: the caller moves it)
+    }
+    return stop;
+}
+// the chain of a Snappy block (hb_lz4_region.hip): regions, parses, beliefs, verification -- RgPlan.ok / RgRegion.{entry, exit, opos} as for LZ4.
+// w: rg_layout(cap).total bytes; entry0: device pointer to the stream position of the first element (SnPlan.hdr)
+int hb_launch_snappy_region_chain(const uint8_t *src, size_t n, size_t cap, uint8_t *w, const uint32_t *entry0, hipStream_t s);
+
 // Window-parallel token parser for the passes that copy nothing.  Like dec_fill (hb_dec_common.h), but every lane also sums
 // multi-byte length extensions itself (up to 24 bytes each, i.e. lengths up to 6 KiB): a stream made of long runs (20-byte
 // sequences, each with a 16-byte match extension) would otherwise go through the one-token path sequence by sequence.

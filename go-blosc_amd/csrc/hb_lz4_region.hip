@@ -39,11 +39,12 @@ bool hb_lz4_region_wanted(const hb_dec_args &a) {
     return !a.index && !a.memcpy_payload && hb_indexless_parallel(a.n, a.cap) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull && a.n <= a.cap + a.cap / 255 + 16;
 }
 
-__device__ __forceinline__ void k_rg_init_body(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs, const uint32_t bx_, const uint32_t gx_) {
+// entry0: where the chain begins (an LZ4 block: its first byte; a Snappy block: behind the uvarint, SnPlan.hdr)
+__device__ __forceinline__ void k_rg_init_body(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs, const uint32_t bx_, const uint32_t gx_, const uint32_t entry0 = 0u) {
     (void)bx_; (void)gx_;
     const uint32_t r = bx_ * blockDim.x + threadIdx.x;
     if (r == 0) {
-        plan->pad[1] = 0; plan->pad[2] = 0;
+        plan->pad[1] = 0; plan->pad[2] = 0; plan->pad[3] = entry0;
         plan->ok = 0; plan->fail = 0; plan->nreg = nreg; plan->rs = rs; plan->total = 0;
         uint32_t sh = 0; while (((uint64_t)RG_BUCKETS << sh) < rs) sh++;      // RG_BUCKETS << sh >= rs: every position of a region has a bucket
         plan->pad[0] = sh;
@@ -52,8 +53,10 @@ __device__ __forceinline__ void k_rg_init_body(RgPlan *plan, RgRegion *reg, uint
     RgRegion R;
     R.b = r * rs; R.entry = R.b; R.exit = RG_INVALID; R.outlen = 0; R.entry0 = R.b; R.exit0 = RG_INVALID; R.outlen0 = 0; R.ntrace = 0;
     R.needfull = 1; R.pad0 = R.b; R.opos = 0; R.pad1[0] = RG_INVALID; R.pad1[1] = R.pad1[2] = R.pad1[3] = 0;
+    if (r == 0) { R.entry = entry0; R.entry0 = entry0; R.pad0 = entry0; }
     reg[r] = R;
 }
+__global__ void k_rg_init_sn(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs, const uint32_t *__restrict__ entry0) { k_rg_init_body(plan, reg, nreg, rs, blockIdx.x, gridDim.x, *entry0 < rs ? *entry0 : 0u); }
 __global__ void k_rg_init(RgPlan *plan, RgRegion *reg, uint32_t nreg, uint32_t rs) { k_rg_init_body(plan, reg, nreg, rs, blockIdx.x, gridDim.x); }
 __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_init_body(j.plan, j.reg, j.nreg, j.rs, blockIdx.x, gridDim.x); }
 
@@ -67,6 +70,7 @@ __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jo
 // parses region r from its believed first token (reg[r].entry) to the first token at / after the next region's start; one wavefront.
 // first: nothing is on record yet.  s_win: RG_PWIN + 128 bytes, s_tq: DTQ entries, both this wave's own.
 // tok / tokcap: the token store (hb_lz4_region.h), or NULL.
+template <int CODEC = RG_LZ4>
 __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src, const uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, const uint32_t r,
                                                 const int first, uint8_t *s_win, uint2 *s_tq, const int lane, uint2 *tok = nullptr, const uint32_t tokcap = 0) {
     const uint32_t nreg = plan->nreg;
@@ -106,7 +110,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             wave_sync();
         };
         wave_sync();
-        if (first && r != 0u) {
+        if (CODEC == RG_LZ4 && first && r != 0u) {
             // A better first guess than "a token starts at my first byte".  Where literal runs are long, tokens are rare and a parse that
             // starts inside literal bytes may not meet one for the whole region (measured on this library's own streams: the exits
             // of 36 % of the regions wrong after the first pass, in chains of up to 15 regions); where the stream is periodic (a
@@ -204,9 +208,10 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             // token with a longer extension, and where the stream is made of those (a plane of runs: one 19-byte sequence per 4 KiB chunk) a region
             // is a latency chain of window passes per token (measured with lean alone: 8.5 ms instead of 1.2 -- 40 such regions of 16 384 are
             // the launch).  So a longer extension switches to the fat parser, which stays until RG_FAT_HOLD windows in a row met none.
-            const bool fat = !RG_LEAN_PARSE || fat_hold != 0u;
+            const bool fat = CODEC != RG_LZ4 || !RG_LEAN_PARSE || fat_hold != 0u;
             bool stop, refat = false;
-            if (fat) stop = rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
+            if constexpr (CODEC == RG_SNAPPY) stop = sn_rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);        // (elements: entry = {position, output bytes})
+            else if (fat) stop = rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
             else stop = dec_fill_lean(s_win, wsh, wlen, wlen, rel, nq, s_tq, lane, last_ntok);
             if (fat_hold) fat_hold--;
             bool done = false;
@@ -238,7 +243,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 const uint64_t ap = wpos + (e.x & 0xFFFFu);
                 const unsigned long long over = hb_ballot((uint32_t)lane < cntb && ap >= bnext);
                 const uint32_t cnt = over ? (uint32_t)__builtin_ctzll(over) : cntb;
-                const uint32_t olen = (uint32_t)lane < cnt ? lit + mlen : 0u;
+                const uint32_t olen = (uint32_t)lane < cnt ? (CODEC == RG_SNAPPY ? e.y : lit + mlen) : 0u;
                 const uint32_t incl = wave_incl_scan_dpp(olen);
                 const uint32_t idx = ntok + (uint32_t)lane;
                 // trace: the first RG_DENSE tokens, and the first token that starts in each bucket of the region's stream range
@@ -280,24 +285,38 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             if (refat) { si = wpos + rel; continue; }
             const bool moved = (wpos + rel) != si;
             si = wpos + rel;
+            if (CODEC == RG_SNAPPY && si > n_src) { invalid = true; break; }     // (a literal that runs off the stream: a stray parse, or a corrupt block)
             if (moved && !stop) continue;
             if (si >= bnext) continue;
             if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src) continue;      // stopped at the window edge: refill first
             // ---- one token the slow way: length extensions of any size ----
+            uint32_t tokstart, ll, ml = 0;
+            uint64_t p;
+            if constexpr (CODEC == RG_SNAPPY) {
+                // (an element near the window's edge, or a literal whose length takes three or four bytes)
+                if (si < wpos || si + 8u > wpos + wlen) refill(si);
+                rel = (uint32_t)(si - wpos);
+                tokstart = (uint32_t)si;
+                SnElem e;
+                if (!sn_parse_uniform(s_win + wsh + rel, n_src - si, e)) { invalid = true; break; }
+                p = si + e.hdr;
+                if (e.lit > n_src - p || e.lit > 0xFFFFFFF0ull) { invalid = true; break; }
+                p += e.lit;
+                ll = (uint32_t)e.lit; ml = e.mlen;
+            } else {
             if (si < wpos || si >= wpos + wlen) refill(si);
             rel = (uint32_t)(si - wpos);
-            const uint32_t tokstart = (uint32_t)si;
+            tokstart = (uint32_t)si;
             const uint32_t tok = RFL((uint32_t)s_win[wsh + rel]);
             rel++;
-            uint32_t ll = tok >> 4;
+            ll = tok >> 4;
             {
                 const uint64_t span = n_src - wpos;
                 if (ll == 15u && !dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel, ll, lane)) { invalid = true; break; }
             }
-            uint64_t p = wpos + rel;
+            p = wpos + rel;
             if ((uint64_t)ll > n_src - p) { invalid = true; break; }
             p += ll;
-            uint32_t ml = 0;
             if (p != n_src) {                                           // (p == n_src: the block's final, literal-only sequence)
                 if (n_src - p < 2) { invalid = true; break; }
                 p += 2;
@@ -309,6 +328,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                     if (!dec_read_ext(s_win + wsh, 0, 0u, wlen, src + wpos, (uint32_t)(span < 0xFFFFFFF0ull ? span : 0xFFFFFFF0ull), rel2, ml, lane)) { invalid = true; break; }
                     p = wpos + rel2;
                 }
+            }
             }
             {
                 const uint32_t bk = (tokstart - rb) >> bsh;
@@ -328,7 +348,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             out += (uint64_t)ll + ml;
             ntok++;
             si = p;
-            if (ll >= 270u || ml >= 274u) fat_hold = RG_FAT_HOLD;
+            if (CODEC == RG_LZ4 && (ll >= 270u || ml >= 274u)) fat_hold = RG_FAT_HOLD;
             if (out > 0xFFFFFFF0ull) { invalid = true; break; }
         }
         if (out > 0xFFFFFFF0ull) invalid = true;
@@ -348,6 +368,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
     }
 }
 
+template <int CODEC = RG_LZ4>
 __device__ __forceinline__ void k_rg_parse_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first, uint2 *tok, uint32_t tokcap, const uint32_t bx_, const uint32_t gx_) {
     (void)bx_; (void)gx_;
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
@@ -361,7 +382,7 @@ __device__ __forceinline__ void k_rg_parse_body(const uint8_t *__restrict__ src,
         const uint64_t t0 = wall_clock64();
         const uint32_t had0 = RFL(reg[r].exit0);
 #endif
-        rg_parse_region(src, n_src, plan, reg, traces, r, first, s_win, s_tq, lane, tok, tokcap);
+        rg_parse_region<CODEC>(src, n_src, plan, reg, traces, r, first, s_win, s_tq, lane, tok, tokcap);
         wave_sync();
 #ifdef RG_DEBUG_TIMES
         if (!first && lane == 0) { reg[r].pad1[3] += (uint32_t)((wall_clock64() - t0) / 100); reg[r].pad1[2] = had0 == RG_INVALID ? 2u : 1u; }     // microseconds; re-parse kind
@@ -369,7 +390,51 @@ __device__ __forceinline__ void k_rg_parse_body(const uint8_t *__restrict__ src,
     }
 }
 __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first, uint2 *tok, uint32_t tokcap) { k_rg_parse_body(src, n_src, plan, reg, traces, first, tok, tokcap, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void k_snr_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first) { k_rg_parse_body<RG_SNAPPY>(src, n_src, plan, reg, traces, first, nullptr, 0u, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(64) void k_rg_parse_b(const RgJob *__restrict__ jobs, int first) { const RgJob j = jobs[blockIdx.y]; k_rg_parse_body(j.src, j.n_src, j.plan, j.reg, j.traces, first, j.tok, j.tokcap, blockIdx.x, gridDim.x); }
+
+// one token (LZ4 sequence / Snappy element) at stream position p, by one lane: p moves behind it, cum grows by its output bytes; false: it runs off
+// the stream or is malformed (the caller then asks for a wave-parallel parse, which decides)
+template <int CODEC>
+__device__ __forceinline__ bool rg_step_serial(const uint8_t *__restrict__ src, const uint64_t n_src, uint64_t &p, uint64_t &cum) {
+    if constexpr (CODEC == RG_SNAPPY) {
+        if (p >= n_src) return false;
+        const uint32_t t = src[p], kind = t & 3u, x = t >> 2;
+        uint64_t hdr = 1, lit = 0, ml = 0;
+        if (kind == 0u) {
+            if (x < 60u) lit = x + 1u;
+            else {
+                const uint32_t nb = x - 59u;
+                if (n_src - p < 1u + nb) return false;
+                uint64_t v = 0;
+                for (uint32_t i = 0; i < nb; i++) v |= (uint64_t)src[p + 1u + i] << (8u * i);
+                lit = v + 1u; hdr = 1u + nb;
+            }
+        } else if (kind == 1u) { hdr = 2; ml = 4u + (x & 7u); }
+        else if (kind == 2u) { hdr = 3; ml = 1u + x; }
+        else { hdr = 5; ml = 1u + x; }
+        if (n_src - p < hdr || lit > n_src - p - hdr) return false;
+        p += hdr + lit; cum += lit + ml;
+        return true;
+    } else {
+        const uint32_t tok = src[p];
+        uint64_t q = p + 1, ll = tok >> 4;
+        bool bad = false;
+        if (ll == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ll += x; if (x != 255u) break; } }
+        if (bad || ll > n_src - q) return false;
+        q += ll;
+        uint64_t ml = 0;
+        if (q != n_src) {
+            if (n_src - q < 2) return false;
+            q += 2; ml = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ml += x; if (x != 255u) break; } }
+            if (bad) return false;
+        }
+        cum += ll + ml;
+        p = q;
+        return true;
+    }
+}
 
 // ---- (1b) settle the chain.  Belief of every region about its first token: the furthest position any predecessor's parse reaches (an
 // exclusive prefix maximum of the exits).  On the true chain exits are monotone, so this is the predecessor's exit; a token that
@@ -382,7 +447,7 @@ __global__ __launch_bounds__(64) void k_rg_parse_b(const RgJob *__restrict__ job
 // true chain by themselves (periodic data: stray and true chains run side by side), so that every region has to wait for its
 // predecessor's exit and be parsed from there.  Launch pairs would cost more than the hops: this kernel parses the regions that
 // ask for it itself (RG_FPARSERS wavefronts) and goes on, until nothing moves or RG_MAXHOPS.
-template <bool FINISH, uint32_t MAXR>
+template <bool FINISH, uint32_t MAXR, int CODEC = RG_LZ4>
 __device__ __forceinline__ void k_rg_settle_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, const uint32_t bx_, const uint32_t gx_) {
     (void)bx_; (void)gx_;
     // (LDS: entry + exit of every region, one bit per region for "waits for a full parse"; output lengths stay in global memory --
@@ -451,22 +516,7 @@ __device__ __forceinline__ void k_rg_settle_body(const uint8_t *__restrict__ src
                         if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
                         else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
                         if (cum0 != RG_INVALID) { s_exit[r] = exit0; reg[r].outlen = (uint32_t)(cum + (outlen0 - cum0)); set_need(r, false); reg[r].pad0 = (uint32_t)p; settled = true; break; }
-                        // one token, serially
-                        const uint32_t tok = src[p];
-                        uint64_t q = p + 1, ll = tok >> 4;
-                        bool bad = false;
-                        if (ll == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ll += x; if (x != 255u) break; } }
-                        if (bad || ll > n_src - q) break;
-                        q += ll;
-                        uint64_t ml = 0;
-                        if (q != n_src) {
-                            if (n_src - q < 2) break;
-                            q += 2; ml = (tok & 15u) + 4u;
-                            if ((tok & 15u) == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ml += x; if (x != 255u) break; } }
-                            if (bad) break;
-                        }
-                        cum += ll + ml;
-                        p = q;
+                        if (!rg_step_serial<CODEC>(src, n_src, p, cum)) break;     // one token, serially
                     }
                     if (!settled) { s_exit[r] = RG_INVALID; set_need(r, true); s_pend = 1; }     // k_rg_parse takes it from `entry`
                 }
@@ -492,7 +542,7 @@ __device__ __forceinline__ void k_rg_settle_body(const uint8_t *__restrict__ src
         if (nl == 0u && !capped) break;                                 // nothing waits, nothing moves: done
         const uint32_t w = (uint32_t)t >> 6;
         if (w < RG_FPARSERS)
-            for (uint32_t i = w; i < nl; i += RG_FPARSERS) { rg_parse_region(src, n_src, plan, reg, traces, s_list[i], 0, s_pwin[w], s_ptq[w], t & 63); wave_sync(); }
+            for (uint32_t i = w; i < nl; i += RG_FPARSERS) { rg_parse_region<CODEC>(src, n_src, plan, reg, traces, s_list[i], 0, s_pwin[w], s_ptq[w], t & 63); wave_sync(); }
         __threadfence_block();
         __syncthreads();
         if ((uint32_t)t < nl) {
@@ -511,6 +561,8 @@ __device__ __forceinline__ void k_rg_settle_body(const uint8_t *__restrict__ src
 }
 template <bool FINISH>
 __global__ __launch_bounds__(1024) void k_rg_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces) { k_rg_settle_body<FINISH, RG_MAXREG>(src, n_src, plan, reg, traces, blockIdx.x, gridDim.x); }
+template <bool FINISH>
+__global__ __launch_bounds__(1024) void k_snr_settle(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces) { k_rg_settle_body<FINISH, RG_MAXREG, RG_SNAPPY>(src, n_src, plan, reg, traces, blockIdx.x, gridDim.x); }
 template <bool FINISH>
 __global__ __launch_bounds__(1024) void k_rg_settle_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_settle_body<FINISH, RGB_MAXR>(j.src, j.n_src, j.plan, j.reg, j.traces, blockIdx.x, gridDim.x); }
 
@@ -546,6 +598,7 @@ __device__ __forceinline__ void k_rg_pmax_body(RgPlan *plan, const RgRegion *reg
 }
 __global__ __launch_bounds__(1024) void k_rg_pmax(RgPlan *plan, const RgRegion *reg, uint32_t *pmax) { k_rg_pmax_body(plan, reg, pmax, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(1024) void k_rg_pmax_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_pmax_body(j.plan, j.reg, j.pmax, blockIdx.x, gridDim.x); }
+template <int CODEC = RG_LZ4>
 __device__ __forceinline__ void k_rg_fix_body(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces, const uint32_t *__restrict__ pmax, const uint32_t bx_, const uint32_t gx_) {
     (void)bx_; (void)gx_;
     const uint32_t nreg = plan->nreg, bsh = plan->pad[0];
@@ -569,25 +622,12 @@ __device__ __forceinline__ void k_rg_fix_body(const uint8_t *__restrict__ src, u
         if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
         else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
         if (cum0 != RG_INVALID) { R->exit = exit0; R->outlen = (uint32_t)(cum + (outlen0 - cum0)); R->needfull = 0; R->pad0 = (uint32_t)p; return; }
-        const uint32_t tok = src[p];
-        uint64_t q = p + 1, ll = tok >> 4;
-        bool bad = false;
-        if (ll == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ll += x; if (x != 255u) break; } }
-        if (bad || ll > n_src - q) break;
-        q += ll;
-        uint64_t ml = 0;
-        if (q != n_src) {
-            if (n_src - q < 2) break;
-            q += 2; ml = (tok & 15u) + 4u;
-            if ((tok & 15u) == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ml += x; if (x != 255u) break; } }
-            if (bad) break;
-        }
-        cum += ll + ml;
-        p = q;
+        if (!rg_step_serial<CODEC>(src, n_src, p, cum)) break;
     }
     R->exit = RG_INVALID; R->needfull = 1; plan->pad[1] = 1;            // k_rg_parse takes it from `entry`
 }
 __global__ __launch_bounds__(64) void k_rg_fix(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces, const uint32_t *__restrict__ pmax) { k_rg_fix_body(src, n_src, plan, reg, traces, pmax, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(64) void k_snr_fix(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, const uint2 *traces, const uint32_t *__restrict__ pmax) { k_rg_fix_body<RG_SNAPPY>(src, n_src, plan, reg, traces, pmax, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(64) void k_rg_fix_b(const RgJob *__restrict__ jobs) { const RgJob j = jobs[blockIdx.y]; k_rg_fix_body(j.src, j.n_src, j.plan, j.reg, j.traces, j.pmax, blockIdx.x, gridDim.x); }
 
 // ---- (1c) verify the chain, give every region its output position ----
@@ -607,7 +647,7 @@ __device__ __forceinline__ void k_rg_scan_body(RgPlan *plan, RgRegion *reg, uint
         if (r < nreg) {
             const RgRegion R = reg[r];
             bool ok = !R.needfull && R.exit != RG_INVALID;
-            ok = ok && (r == 0 ? R.entry == 0u : R.entry == reg[r - 1].exit);
+            ok = ok && (r == 0 ? R.entry == plan->pad[3] : R.entry == reg[r - 1].exit);
             if (r + 1 == nreg) ok = ok && R.exit == (uint32_t)n_src;
             if (!ok) atomicOr(&bad, 1u);
             mine[k] = R.outlen;
@@ -991,6 +1031,35 @@ int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size
     hb_prof_end(s);
     HB_HIP_TRY(hipGetLastError());
     *index = idx; *index_bytes = ib;
+    return HB_OK;
+}
+
+
+// ---- the chain of a Snappy block: the same kernels with the element parser; what follows (units, decode) is hb_snappy.hip's ----
+int hb_launch_snappy_region_chain(const uint8_t *src, size_t n, size_t cap, uint8_t *w, const uint32_t *entry0, hipStream_t s) {
+    const RgLayout L = rg_layout(cap);
+    RgPlan *plan = (RgPlan *)(w + L.plan);
+    RgRegion *reg = (RgRegion *)(w + L.reg);
+    uint2 *traces = (uint2 *)(w + L.trace);
+    uint32_t *pmax = (uint32_t *)(w + L.pmax);
+    uint64_t rs; uint32_t nreg;
+    rg_regions(n, &rs, &nreg);
+    hb_prof_begin("k_snr_parse", s);
+    hipLaunchKernelGGL(k_rg_init_sn, dim3((nreg + 255) / 256), dim3(256), 0, s, plan, reg, nreg, (uint32_t)rs, entry0);
+    hipLaunchKernelGGL(k_snr_parse, dim3(nreg), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, 1);
+    hb_prof_end(s);
+    hb_prof_begin("k_snr_settle", s);
+    hipLaunchKernelGGL(k_rg_pmax, dim3(1), dim3(1024), 0, s, plan, reg, pmax);
+    hipLaunchKernelGGL(k_snr_fix, dim3((nreg + 63) / 64), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, (const uint32_t *)pmax);
+    hipLaunchKernelGGL(k_snr_parse, dim3(nreg), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, 0);
+    for (int k = 0; k < RG_FIXROUNDS; k++) {
+        hipLaunchKernelGGL(k_snr_settle<false>, dim3(1), dim3(1024), 0, s, src, (uint64_t)n, plan, reg, traces);
+        hipLaunchKernelGGL(k_snr_parse, dim3(nreg < 1024u ? nreg : 1024u), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, 0);
+    }
+    hipLaunchKernelGGL(k_snr_settle<true>, dim3(1), dim3(1024), 0, s, src, (uint64_t)n, plan, reg, traces);
+    hipLaunchKernelGGL(k_rg_scan, dim3(1), dim3(1024), 0, s, plan, reg, (uint64_t)n, (uint64_t)cap);
+    hb_prof_end(s);
+    HB_HIP_TRY(hipGetLastError());
     return HB_OK;
 }
 

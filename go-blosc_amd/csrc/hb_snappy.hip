@@ -23,9 +23,10 @@
 //       written by the reference): 64 KiB of history in LDS, copies that reach further back read the output in HBM.
 #include "hb_lz4.h"
 #include "hb_dec_common.h"
+#include "hb_lz4_region.h"
 
 struct SnPlan {
-    uint32_t mode;        // 0 = serial, 1 = indexed
+    uint32_t mode;        // 0 = serial, 1 = indexed (4 KiB units, stored index), 2 = blocks (64 KiB units found by the discovery)
     uint32_t fail;
     uint32_t nunits;
     uint32_t nbytes;      // declared (uvarint) length
@@ -51,6 +52,7 @@ __global__ void k_sn_dec_plan(const uint8_t *__restrict__ src, uint64_t n_src, c
     result->status = HB_OK; result->flags = 0; result->bytes = 0; result->total_bytes = 0; result->reserved = 0;
     uint64_t dlen; uint32_t hl;
     if (!sn_uvarint(src, n_src, dlen, hl) || dlen > 0xFFFFFFFFull) return;      // the serial kernel reports the error
+    if (dlen <= cap) { plan->nbytes = (uint32_t)dlen; plan->hdr = hl; }           // (the block-parallel path of index-less blocks starts from these)
     if (!index || index_bytes < HB_SNX_HDR_BYTES + 2 * HB_SNX_ENTRY) return;
     uint32_t h[8];
     for (int i = 0; i < 8; i++) h[i] = ld4u(index + 4 * i);
@@ -122,29 +124,7 @@ __device__ __forceinline__ bool sn_fill(const uint8_t *s_in, const uint32_t sh, 
     return stop;
 }
 
-// one element the slow way, all values wave-uniform: returns false on a malformed element.  `in[k]` = stream byte k of a
-// buffer holding `avail` bytes from position 0.  kind / lit / mlen / off / hdr describe the element at `at`.
-struct SnElem { uint32_t kind, hdr; uint64_t lit; uint32_t mlen; uint64_t off; };
-__device__ __forceinline__ bool sn_parse_uniform(const uint8_t *p, uint64_t avail, SnElem &e) {
-    if (avail < 1) return false;
-    const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)p[0]);
-    e.kind = t & 3u; e.lit = 0; e.mlen = 0; e.off = 0; e.hdr = 1;
-    const uint32_t x = t >> 2;
-    auto byte = [&](uint32_t i) { return (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)p[i]); };
-    if (e.kind == 0u) {
-        if (x < 60u) e.lit = x + 1u;
-        else {
-            const uint32_t nb = x - 59u;                          // 1..4 length bytes
-            if (avail < 1u + nb) return false;
-            uint64_t v = 0;
-            for (uint32_t i = 0; i < nb; i++) v |= byte(1u + i) << (8u * i);
-            e.lit = v + 1u; e.hdr = 1u + nb;
-        }
-    } else if (e.kind == 1u) { if (avail < 2) return false; e.mlen = 4u + (x & 7u); e.off = ((uint64_t)(t >> 5) << 8) | byte(1); e.hdr = 2; }
-    else if (e.kind == 2u) { if (avail < 3) return false; e.mlen = 1u + x; e.off = byte(1) | (byte(2) << 8); e.hdr = 3; }
-    else { if (avail < 5) return false; e.mlen = 1u + x; e.off = byte(1) | (byte(2) << 8) | (byte(3) << 16) | (byte(4) << 24); e.hdr = 5; }
-    return true;
-}
+// (one element the slow way: sn_parse_uniform, hb_lz4_region.h)
 
 __global__ __launch_bounds__(64) void k_sn_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src, uint8_t *__restrict__ dst,
                                                        const uint8_t *__restrict__ index, SnPlan *plan) {
@@ -156,7 +136,6 @@ __global__ __launch_bounds__(64) void k_sn_dec_indexed(const uint8_t *__restrict
     const uint32_t nunits = plan->nunits, nbytes = plan->nbytes, hl = plan->hdr;
     const uint8_t *ent = index + HB_SNX_HDR_BYTES;
     for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
-#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
         const uint32_t s0 = RFL(ld4u(ent + 4 * (size_t)u)), s1 = RFL(ld4u(ent + 4 * (size_t)(u + 1)));
         const uint32_t d0 = u * HB_CHUNK, outlen = min(HB_CHUNK, nbytes - d0);
         bool ok = s0 >= hl && s0 <= s1 && s1 <= n_src && (s1 - s0) <= SN_IN_MAX;
@@ -214,7 +193,6 @@ __global__ __launch_bounds__(64) void k_sn_dec_indexed(const uint8_t *__restrict
         const uint32_t done_b = head + body * 16u;
         if (done_b + lane < outlen) o[done_b + lane] = s_out[done_b + lane];
         wave_sync();
-#undef RFL
     }
 }
 
@@ -232,7 +210,7 @@ __global__ __launch_bounds__(64) void k_sn_dec_serial(const uint8_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t s_img[SNS_HIST + SNS_PAGE + 1024];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     const int lane = threadIdx.x;
-    if (plan->mode == 1 && !plan->fail) {
+    if ((plan->mode == 1 || plan->mode == 2) && !plan->fail) {
         if (lane == 0) {
             const uint64_t got = plan->nbytes;
             result->flags = 1; result->bytes = got; result->total_bytes = got;
@@ -364,6 +342,196 @@ __global__ __launch_bounds__(64) void k_sn_dec_serial(const uint8_t *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Blocks without an index (written by any other Snappy encoder -- the reference's frames, codec.go:228-235): block-parallel decode.
+// Every Snappy encoder in use compresses its input in blocks of 64 KiB that share nothing (golang/snappy, libsnappy: the hash table is reset per
+// block and the remaining literals are emitted at its end), so the element stream is a concatenation of sub-streams that decode to exactly 64 KiB
+// each and copy only from themselves -- but nothing in the stream says where they begin.  The token discovery of hb_lz4_region.hip finds and
+// VERIFIES the element chain (same kernels, element parser: hb_launch_snappy_region_chain); k_snr_units walks it once more with output positions
+// and notes the element that starts at every multiple of 64 KiB of output; k_sn_dec_blocks decodes one such unit per wavefront (64 KiB image in
+// LDS).  Nothing is assumed: a unit must consume exactly its slice, produce exactly its bytes, and no copy may reach in front of it -- an encoder
+// that matches across 64 KiB (klauspost's s2.EncodeSnappy on one large block does) fails that test, and the single wavefront decodes the block.
+// ------------------------------------------------------------------------------------------------------------
+#define SNB_UNIT 65536u
+#define SNB_WIN  4096u
+
+// the verified chain of region r, elements 64 at a time: f(cnt, pos, olen, opos) -- lane < cnt holds the element at stream position pos that
+// produces olen bytes at output position opos (64-bit); returns false when the walk leaves the stream (cannot happen on a verified chain)
+template <class F>
+__device__ __forceinline__ bool snr_walk(const uint8_t *__restrict__ src, const uint64_t n_src, const uint64_t start, const uint64_t exitp, const uint64_t opos0,
+                                         uint8_t *s_win, uint2 *s_tq, const int lane, F &&f) {
+    uint64_t si = start, wpos = 0, out = opos0;
+    uint32_t wlen = 0, wsh = 0, nq = 0;
+    auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+        const uint8_t *g = src + at;
+        wsh = (uint32_t)((uintptr_t)g & 15u);
+        const uint64_t left = n_src - at;
+        wlen = (uint32_t)(left < (uint64_t)(RG_PWIN - 16u) ? left : (uint64_t)(RG_PWIN - 16u));
+        const u32x4 *ga = (const u32x4 *)(g - wsh);
+        const uint32_t nv = (wsh + wlen + 15u) >> 4;
+        wave_sync();
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+        wpos = at;
+        wave_sync();
+    };
+    wave_sync();
+    for (;;) {
+        if (si >= exitp) return true;
+        if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+        uint32_t rel = (uint32_t)(si - wpos);
+        const bool stop = sn_rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
+        while (nq > 0u) {
+            const uint32_t cntb = nq < 64u ? nq : 64u;
+            const uint2 e = s_tq[lane];
+            const uint64_t ap = wpos + e.x;
+            const unsigned long long over = hb_ballot((uint32_t)lane < cntb && ap >= exitp);
+            const uint32_t cnt = over ? (uint32_t)__builtin_ctzll(over) : cntb;
+            const uint32_t olen = (uint32_t)lane < cnt ? e.y : 0u;
+            const uint32_t incl = wave_incl_scan_dpp(olen);
+            f(cnt, ap, olen, out + (incl - olen));
+            out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+            if (over) return true;
+            const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
+            nq -= cntb;
+            if ((uint32_t)lane < nq) s_tq[lane] = rest;
+        }
+        const bool moved = (wpos + rel) != si;
+        si = wpos + rel;
+        if (si > n_src) return false;
+        if (moved && !stop) continue;
+        if (si >= exitp) continue;
+        if (moved && si - wpos + 1024u > wlen && wpos + wlen < n_src) continue;
+        if (si < wpos || si + 8u > wpos + wlen) refill(si);
+        rel = (uint32_t)(si - wpos);
+        SnElem e;
+        if (!sn_parse_uniform(s_win + wsh + rel, n_src - si, e)) return false;
+        const uint64_t p = si + e.hdr;
+        if (e.lit > n_src - p || e.lit > 0xFFFFFFF0ull) return false;
+        f(1u, si, (uint32_t)e.lit + e.mlen, out);
+        out += e.lit + e.mlen;
+        si = p + e.lit;
+    }
+}
+
+// units[u] = 1 + stream position of the element that starts at output position u * SNB_UNIT (0: none); an element that crosses such a position: fail
+__global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *rgplan, const RgRegion *__restrict__ reg, uint32_t *__restrict__ units) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    const int lane = threadIdx.x;
+    if (!rgplan->ok) return;
+    const uint32_t nreg = rgplan->nreg;
+    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+        const uint32_t entry = RFL(reg[r].entry), exitp = RFL(reg[r].exit);
+        if (entry >= exitp) continue;                                    // no element of the chain starts in this region
+        const uint64_t opos = reg[r].opos;
+        bool bad = false;
+        const bool through = snr_walk(src, n_src, entry, exitp, opos, s_win, s_tq, lane, [&](uint32_t cnt, uint64_t pos, uint32_t olen, uint64_t o) __attribute__((always_inline)) {
+            if ((uint32_t)lane < cnt && olen) {
+                if ((o & (SNB_UNIT - 1u)) == 0u) units[o / SNB_UNIT] = (uint32_t)pos + 1u;
+                else if ((o / SNB_UNIT) != ((o + olen - 1u) / SNB_UNIT)) bad = true;
+            }
+        });
+        if (hb_ballot(bad) || !through) { if (lane == 0) atomicExch(&rgplan->fail, 1u); }
+        wave_sync();
+    }
+}
+
+// 1 thread: the chain verified, its output is what the block declares, no element crosses a unit boundary -> mode 2
+__global__ void k_snr_gate(const RgPlan *__restrict__ rgplan, SnPlan *plan, uint32_t *__restrict__ units, uint64_t n_src) {
+    if (plan->mode != 0 || !rgplan->ok || rgplan->fail || plan->hdr == 0u || plan->nbytes == 0u) return;
+    if (rgplan->total != (uint64_t)plan->nbytes) return;                 // fewer / more bytes than declared: the serial decoder reports it
+    const uint32_t nunits = (plan->nbytes + SNB_UNIT - 1u) / SNB_UNIT;
+    units[nunits] = (uint32_t)n_src + 1u;
+    plan->nunits = nunits;
+    plan->mode = 2;
+}
+
+__global__ __launch_bounds__(64) void k_sn_dec_blocks(const uint8_t *__restrict__ src, uint64_t n_src, uint8_t *__restrict__ dst, const uint32_t *__restrict__ units, SnPlan *plan) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[SNB_WIN + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[SNB_UNIT + 1024];
+    __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    if (plan->mode != 2) return;
+    const int lane = threadIdx.x;
+    const uint32_t nunits = plan->nunits, nbytes = plan->nbytes;
+    for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const uint32_t a0 = RFL(units[u]), a1 = RFL(units[u + 1]);
+        const uint64_t d0 = (uint64_t)u * SNB_UNIT;
+        const uint32_t outlen = (uint32_t)(((uint64_t)nbytes - d0) < (uint64_t)SNB_UNIT ? ((uint64_t)nbytes - d0) : (uint64_t)SNB_UNIT);
+        bool ok = a0 != 0u && a1 != 0u && a0 < a1 && (uint64_t)(a1 - 1u) <= n_src;
+        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
+        const uint64_t s0 = a0 - 1u, s1 = a1 - 1u;
+        uint64_t si = s0, wpos = 0;
+        uint32_t wlen = 0, wsh = 0, nq = 0, di = 0;
+        auto refill = [&](uint64_t at) __attribute__((always_inline)) {     // the window never reaches beyond the unit's slice
+            const uint8_t *g = src + at;
+            wsh = (uint32_t)((uintptr_t)g & 15u);
+            const uint64_t left = s1 - at;
+            wlen = (uint32_t)(left < (uint64_t)(SNB_WIN - 16u) ? left : (uint64_t)(SNB_WIN - 16u));
+            const u32x4 *ga = (const u32x4 *)(g - wsh);
+            const uint32_t nv = (wsh + wlen + 15u) >> 4;
+            wave_sync();
+            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+            wpos = at;
+            wave_sync();
+        };
+        wave_sync();
+        while (ok && si < s1) {
+            if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
+            uint32_t rel = (uint32_t)(si - wpos);
+            const bool stop = sn_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
+            bool rewound = false;
+            const bool dok = dec_drain(s_win + wsh, 0, s_img, outlen, 0u, di, rel, nq, s_tq, true, rewound, lane);
+            if (!dok || rewound) { ok = false; break; }             // a copy from in front of the unit, or an element that passes its end: not ours to decide
+            const bool moved = (wpos + rel) != si;
+            si = wpos + rel;
+            if (moved && !stop) continue;
+            if (si >= s1) break;
+            if (moved && si - wpos + 1024u > wlen && wpos + wlen < s1) continue;      // stopped at the window edge: refill first
+            // one element the slow way: a literal longer than 511 bytes, a copy with a 4-byte offset
+            if (si < wpos || si + 8u > wpos + wlen) refill(si);
+            rel = (uint32_t)(si - wpos);
+            SnElem e;
+            if (!sn_parse_uniform(s_win + wsh + rel, s1 - si, e)) { ok = false; break; }
+            si += e.hdr;
+            if (e.kind == 0u) {
+                if (e.lit > s1 - si || e.lit > (uint64_t)(outlen - di)) { ok = false; break; }
+                const uint32_t take = (uint32_t)e.lit;
+                const uint8_t *g = src + si;
+                uint32_t k0 = 0;
+                for (; k0 + 4096u <= take; k0 += 4096u) {                // 4 x 16 B per lane in flight
+                    u32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = ld16u(g + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) ((hb_u128u *)(s_img + di + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u))->v = v[q];
+                }
+                for (uint32_t k = k0 + lane; k < take; k += 64) s_img[di + k] = g[k];
+                si += take; di += take;
+                wave_sync();
+            } else {
+                if (e.off == 0 || e.off > (uint64_t)di || e.mlen > outlen - di) { ok = false; break; }
+                wave_sync();
+                dec_match_copy(s_img, di, (uint32_t)e.off, e.mlen, lane);
+                di += e.mlen;
+                wave_sync();
+            }
+        }
+        if (ok) ok = (si == s1) && (di == outlen) && nq == 0u;
+        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); wave_sync(); continue; }
+        wave_sync();
+        uint8_t *o = dst + d0;                                          // flush the unit image: 16-byte stores on an aligned body
+        uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);
+        if (head > outlen) head = outlen;
+        if ((uint32_t)lane < head) o[lane] = s_img[lane];
+        const uint32_t body = (outlen - head) >> 4;
+        if (head == 0) { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + i * 16u) = *(const u32x4 *)(s_img + i * 16u); }
+        else { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + head + i * 16u) = ((const hb_u128u *)(s_img + head + i * 16u))->v; }
+        const uint32_t done_b = head + body * 16u;
+        if (done_b + lane < outlen) o[done_b + lane] = s_img[done_b + lane];
+        wave_sync();
+    }
+}
+
 size_t hb_snappy_dec_workspace(size_t) { return 256; }
 
 int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
@@ -371,6 +539,29 @@ int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
     hb_prof_begin("k_sn_dec_plan", s);
     hipLaunchKernelGGL(k_sn_dec_plan, dim3(1), dim3(1), 0, s, a.src, (uint64_t)a.n, a.index, (uint64_t)a.index_bytes, (uint64_t)a.cap, plan, a.result);
     hb_prof_end(s);
+    // a block without an index that is worth a dozen launches: find the element chain, decode 64 KiB units in parallel (a.work is sized for the LZ4
+    // discovery of a block of a.cap bytes -- hb_lz4_dec_workspace -- which this one fits into)
+    static const bool no_blocks = [] { const char *e = getenv("HIPBLOSC_DEBUG_NO_SNAPPY_BLOCKS"); return e && *e && *e != '0'; }();   // A/B: the single wavefront
+    if (!a.index && !no_blocks && hb_indexless_parallel(a.n, a.cap) && a.n < 0xFFFFFFF0ull && a.cap < 0xFFFFFFF0ull && a.n <= a.cap + a.cap / 255 + 16) {
+        uint8_t *w = a.work + 256;
+        const RgLayout L = rg_layout(a.cap);
+        RgPlan *rgplan = (RgPlan *)(w + L.plan);
+        const RgRegion *reg = (const RgRegion *)(w + L.reg);
+        uint32_t *units = (uint32_t *)(w + L.total);
+        const size_t nunits = (a.cap + SNB_UNIT - 1) / SNB_UNIT;
+        uint64_t rs; uint32_t nreg;
+        rg_regions(a.n, &rs, &nreg);
+        int rc = hb_launch_snappy_region_chain(a.src, a.n, a.cap, w, &plan->hdr, s);
+        if (rc) return rc;
+        HB_HIP_TRY(hipMemsetAsync(units, 0, (nunits + 2) * 4, s));
+        hb_prof_begin("k_snr_units", s);
+        hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units);
+        hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
+        hb_prof_end(s);
+        hb_prof_begin("k_sn_dec_blocks", s);
+        hipLaunchKernelGGL(k_sn_dec_blocks, dim3((unsigned)(nunits < 2048 ? nunits : 2048)), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (const uint32_t *)units, plan);
+        hb_prof_end(s);
+    }
     if (a.index) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;
         const unsigned grid = (unsigned)(units < 1 ? 1 : (units < 256u * 256u ? units : 256u * 256u));

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--typesize", type=int, default=4)
     ap.add_argument("--writer", default="oracle", choices=["oracle", "device"],
                     help="oracle: the restated reference encoder (64 KiB window); device: this library WITHOUT the index trailer")
+    ap.add_argument("--codec", default="lz4", choices=["lz4", "snappy"], help="snappy: the oracle's Snappy encoder (64 KiB blocks) -> element discovery + k_sn_dec_blocks")
     ap.add_argument("--small-work", action="store_true", help="workspace without the symbolic decoder's scratch (foreign frames then decode on one wavefront)")
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--dump", default="", help="lo:hi -- print the final state of these regions")
@@ -41,10 +42,11 @@ def main():
     assert L.hb_init() == 0
     n = a.mib << 20
     x = bench.synth_host(a.dataset, n, 0)
+    codec_o, codec_d = (O.SNAPPY, hb.Snappy) if a.codec == "snappy" else (O.LZ4, hb.LZ4)
     if a.writer == "oracle":
-        f = O.compress_frame(x, shuffle=a.shuffle, typesize=a.typesize)
+        f = O.compress_frame(x, codec=codec_o, shuffle=a.shuffle, typesize=a.typesize)
     else:
-        f = np.frombuffer(hb.Compress(x.tobytes(), hb.LZ4, 5, a.shuffle, a.typesize, opts=0), np.uint8)
+        f = np.frombuffer(hb.Compress(x.tobytes(), codec_d, 5, a.shuffle, a.typesize, opts=0), np.uint8)
     dev = torch.device("cuda", 0)
     d_frame = torch.from_numpy(f.copy()).to(dev)
     pad = torch.zeros(64, dtype=torch.uint8, device=dev)
@@ -65,7 +67,8 @@ def main():
         L.hb_profile_enable(0)
         print(f"rep {rep}: {dt * 1e3:.2f} ms wall with profiling events = {n / dt / 1e9:.1f} GB/s")
     r = res.cpu().numpy().view(np.uint8)
-    print("rc", rc, "status", int(r[:4].view(np.int32)[0]), "flags", int(r[4:8].view(np.uint32)[0]), "bytes", int(r[8:16].view(np.uint64)[0]))
+    print("rc", rc, "status", int(r[:4].view(np.int32)[0]), "flags", int(r[4:8].view(np.uint32)[0]), "bytes", int(r[8:16].view(np.uint64)[0]),
+          "output == input:", bool(np.array_equal(d_out.cpu().numpy(), x.view(np.uint8).reshape(-1))))
     print("ratio", f.size / n, "stage ms", {k: round(sum(v), 3) for k, v in st.items()})
     print("per launch:", {k: [round(x, 3) for x in v] for k, v in st.items() if len(v) > 1})
     w = work.cpu().numpy()
