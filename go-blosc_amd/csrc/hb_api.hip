@@ -357,12 +357,14 @@ int64_t hb_codec_decompress(int codec, const void *src, size_t n, void *dst, siz
     int rc = select_device(device);
     if (rc) return rc;
     Scratch sc(device);
-    const size_t wb = hb_lz4_dec_workspace(cap);
+    const bool par = hb_indexless_parallel(n, cap);                   // (a bare block never has an index: room for the symbolic decoder when it is worth it)
+    const size_t wb = par ? hb_lz4_decompress_workspace_foreign(cap) : hb_lz4_dec_workspace(cap);
     uint8_t *d_src = sc.get(n + 64), *d_dst = sc.get(cap + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));
     if (!d_src || !d_dst || !d_work || !d_res) return HB_ERR_HIP;
     HB_HIP_TRY(hipMemcpy(d_src, src, n, hipMemcpyHostToDevice));
     hb_dec_args a{};
     a.src = d_src; a.n = n; a.dst = d_dst; a.cap = cap; a.work = d_work; a.result = (hb_result *)d_res; a.frame = 0;
+    if (par) a.sym_work = d_work + ((hb_lz4_dec_workspace(cap) + 255) & ~(size_t)255);
     rc = hb_launch_snappy_decode(a, nullptr);
     if (rc) return rc;
     hb_result r;
@@ -491,7 +493,7 @@ int hb_decompress_frame_dev_hdr(const hb_header *hdr, const void *d_frame, size_
     a.staged = staged;
     if (fused_bun || fused_ush) unf = -1;                             // nothing left to do after the decoder
     if (stored_index) { a.index = (const uint8_t *)d_frame + ioff; a.index_bytes = n - ioff; }
-    if (!snappy && work_bytes >= hb_decompress_frame_workspace_foreign(h.nbytes))
+    if (work_bytes >= hb_decompress_frame_workspace_foreign(h.nbytes))
         a.sym_work = work + ((hb_decompress_frame_workspace(h.nbytes) + 255) & ~(size_t)255);
     rc = snappy ? hb_launch_snappy_decode(a, s) : hb_launch_lz4_decode(a, s);
     if (rc) return rc;
@@ -550,8 +552,8 @@ int64_t hb_decompress_frame(const void *frame, size_t n, void *dst, size_t cap, 
     if (rc) return rc;
     if ((size_t)h.nbytes > cap) return HB_ERR_SHORT_BUFFER;
     Scratch sc(device);
-    // an LZ4 frame without an index behind NBytesComp may be anybody's: room for the symbolic decoder as well
-    const bool maybe_foreign = !(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) &&
+    // an LZ4 / Snappy frame without an index behind NBytesComp may be anybody's: room for the symbolic decoder as well
+    const bool maybe_foreign = !(h.flags & HB_FLAG_MEMCPY) && hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) &&
                                n <= (((size_t)h.cbytes + 7) & ~(size_t)7) + 32;
     const size_t wb = maybe_foreign ? hb_decompress_frame_workspace_foreign(h.nbytes) : hb_decompress_frame_workspace(h.nbytes);
     uint8_t *d_frame = sc.get(n + 64), *d_dst = sc.get((size_t)h.nbytes + 64), *d_work = sc.get(wb), *d_res = sc.get(sizeof(hb_result));

@@ -20,7 +20,7 @@ size_t hb_lz4_region_workspace(size_t n_out);
 bool hb_lz4_region_wanted(const hb_dec_args &a);
 int hb_launch_lz4_region_index(const hb_dec_args &a, const uint8_t **index, size_t *index_bytes, hipStream_t s);
 // hb_lz4_sym.hip: decodes a block whose rebuilt index did not hold (a foreign block) from the verified token chain
-int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_work, int mark_post, hipStream_t s);
+int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_work, int mark_post, hipStream_t s, int codec = 0 /* RG_LZ4; 1 = RG_SNAPPY: elements */);
 
 // ---- batches of frames in one set of launches (hb_decompress_frames_batch_dev): frame f of the batch as the kernels see it ----
 struct DecBatchFrame {

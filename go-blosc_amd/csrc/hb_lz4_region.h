@@ -183,6 +183,125 @@ __device__ __forceinline__ bool sn_rg_fill(const uint8_t *s_in, const uint32_t s
     }
     return stop;
 }
+// FILL: 64 lanes parse 64 stream bytes "as if an element started at my byte"; the real chain is walked on the scalar side.
+// Elements go to s_tq as {lsrc | lit << 13 | mlen << 22, offset | pos << 16}.  Returns true when it stopped at the end of the
+// slice or at an element the lane-parallel path does not take (literal longer than 511 bytes, 4-byte offset, too close to lim).
+__device__ __forceinline__ bool sn_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq,
+                                        uint2 *s_tq, const int lane) {
+    bool stop = false;
+    while (nq < 64u && !stop) {
+        if (si == lim) { stop = true; break; }
+        const uint32_t base = si, p = base + (uint32_t)lane;
+        const uint32_t w = dec_read4(s_in, sh + p);
+        const uint32_t t = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, kind = t & 3u, x = t >> 2;
+        bool cplx = p >= lim;
+        uint32_t lit = 0, mlen = 0, offv = 0, hdr = 1;
+        if (kind == 0u) {
+            if (x < 60u) lit = x + 1u;
+            else if (x == 60u) { lit = b1 + 1u; hdr = 2u; }
+            else if (x == 61u) { lit = (b1 | (b2 << 8)) + 1u; hdr = 3u; }
+            else cplx = true;
+            if (lit > 511u) cplx = true;
+        } else if (kind == 1u) { mlen = 4u + (x & 7u); offv = ((t >> 5) << 8) | b1; hdr = 2u; }
+        else if (kind == 2u) { mlen = 1u + x; offv = b1 | (b2 << 8); hdr = 3u; }
+        else cplx = true;
+        const uint32_t lsrc = p + hdr, nxt = lsrc + lit;
+        if (nxt > lim) cplx = true;
+        const unsigned long long cmask = hb_ballot(cplx);
+        unsigned long long tmask = 0;
+        uint32_t cur;
+        {
+            const uint32_t nrel = cplx ? 64u : nxt - base;
+            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
+            uint32_t j = 0, lastj;
+            for (;;) {
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
+                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
+                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
+                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
+                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
+                j = __builtin_amdgcn_readlane(succ, (int)j3);
+                lastj = j3;
+                if (j == j3) break;
+            }
+            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
+            const unsigned long long cm = tmask & cmask;
+            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+        if ((tmask >> lane) & 1ull) {
+            uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
+            s_tq[nq + rank] = e;
+        }
+        nq += (uint32_t)__builtin_popcountll(tmask);
+        si = cur;
+    }
+    return stop;
+}
+
+
+// The verified element chain [start, exitp) of a Snappy block for a decoder, with rg_walk's callbacks (hb_sym_decode.h: the unit decoder of the
+// symbolic pass takes its tokens from either): an element is a token with literals and no match (mlen == 0; `off` is 1 then, a value every check
+// passes) or with a match and no literals.  What sn_fill does not take -- literals of more than 511 bytes or not staged in full -- comes through
+// `single`; a copy from more than 65535 bytes back (4-byte offset: no 64 KiB-block encoder writes one) ends the walk with false.
+template <uint32_t PWIN = RG_PWIN, class Batch, class Single>
+__device__ __forceinline__ bool sn_walk(const uint8_t *__restrict__ src, const uint64_t n_src, const uint32_t start, const uint32_t exitp,
+                                        uint8_t *s_win /* PWIN + 128 */, uint2 *s_tq /* DTQ */, const int lane, Batch &&batch, Single &&single) {
+    uint64_t si = start, wpos = 0;
+    uint32_t wlen = 0, wsh = 0, nq = 0;
+    auto refill = [&](uint64_t at) __attribute__((always_inline)) {
+        const uint8_t *g = src + at;
+        wsh = (uint32_t)((uintptr_t)g & 15u);
+        const uint64_t left = n_src - at;
+        wlen = (uint32_t)(left < (uint64_t)(PWIN - 16u) ? left : (uint64_t)(PWIN - 16u));
+        const u32x4 *ga = (const u32x4 *)(g - wsh);
+        const uint32_t nv = (wsh + wlen + 15u) >> 4;
+        wave_sync();
+        for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
+        wpos = at;
+        wave_sync();
+    };
+    auto drain = [&](const bool all) __attribute__((always_inline)) -> bool {
+        while (nq >= 64u || (all && nq > 0u)) {
+            const uint32_t cntb = nq < 64u ? nq : 64u;
+            const uint2 e = s_tq[lane];                                    // {lsrc | lit << 13 | mlen << 22, offset | pos << 16}, window-relative (sn_fill)
+            const uint32_t lw = e.x & 0x1FFFu, lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22, tw = e.y >> 16;
+            const uint32_t off = mlen ? (e.y & 0xFFFFu) : 1u;
+            const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
+            if (!batch(cntb, (uint32_t)wpos + tw, (uint32_t)wpos + lw, lit, mlen, off, wsh + lw)) return false;
+            nq -= cntb;
+            if ((uint32_t)lane < nq) s_tq[lane] = rest;
+        }
+        return true;
+    };
+    wave_sync();
+    while (si < exitp) {
+        if (si < wpos || si - wpos + PWIN / 4u > wlen) { if (si != wpos || wlen == 0) { if (!drain(true)) return false; refill(si); } }
+        uint32_t rel = (uint32_t)(si - wpos);
+        const uint64_t tolim = (uint64_t)exitp - wpos;
+        const uint32_t lim = (uint32_t)(tolim < (uint64_t)wlen ? tolim : (uint64_t)wlen);
+        const bool stop = sn_fill(s_win, wsh, lim, rel, nq, s_tq, lane);
+        if (!drain(false)) return false;
+        const bool moved = (wpos + rel) != si;
+        si = wpos + rel;
+        if (moved && !stop) continue;
+        if (!drain(true)) return false;
+        if (si >= exitp) break;
+        if (moved && si - wpos + PWIN / 4u > wlen && wpos + wlen < n_src && wpos + wlen < exitp) continue;
+        // ---- one element the slow way ----
+        if (si < wpos || si + 8u > wpos + wlen) refill(si);
+        rel = (uint32_t)(si - wpos);
+        SnElem e;
+        if (!sn_parse_uniform(s_win + wsh + rel, n_src - si, e)) return false;
+        const uint64_t ls = si + e.hdr;
+        if (e.lit > n_src - ls || e.lit > 0xFFFFFFF0ull || e.off > 65535u) return false;
+        if (!single((uint32_t)si, (uint32_t)ls, (uint32_t)e.lit, e.mlen, e.kind == 0u ? 1u : (uint32_t)e.off, 0u)) return false;
+        si = ls + e.lit;
+    }
+    return drain(true);
+}
 // the chain of a Snappy block (hb_lz4_region.hip): regions, parses, beliefs, verification -- RgPlan.ok / RgRegion.{entry, exit, opos} as for LZ4.
 // w: rg_layout(cap).total bytes; entry0: device pointer to the stream position of the first element (SnPlan.hdr)
 int hb_launch_snappy_region_chain(const uint8_t *src, size_t n, size_t cap, uint8_t *w, const uint32_t *entry0, hipStream_t s);

@@ -110,6 +110,25 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             wave_sync();
         };
         wave_sync();
+        if (CODEC == RG_SNAPPY && first && r != 0u) {
+            // A better first guess than "an element starts at my first byte" where it matters: a block the encoder found nothing in is ONE literal
+            // of 65 536 bytes -- F4 FF FF + the block -- twice a region's length, and a parse that starts inside literal bytes hops through them
+            // (any byte is a tag) and past the next header with them: stray and true chain never meet, every such literal is a hop the belief
+            // rounds make one after the other (measured, the 2-bit plane of 1 GiB of shuffled floats: 2048 of them, 443 ms in k_snr_settle and a
+            // chain that did not verify in time).  The header is easy to spot and the parse starts there.  Only a guess: the chain is verified as a whole.
+            uint32_t found = RG_INVALID;
+            for (uint64_t at = start; at < bnext && found == RG_INVALID; at += RG_PWIN - 64u) {
+                refill(at);
+                const uint32_t span = (uint32_t)((bnext - at) < (uint64_t)wlen ? (bnext - at) : (uint64_t)wlen);
+                for (uint32_t k0 = 0; k0 < span && found == RG_INVALID; k0 += 64u) {
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const bool hit = k + 3u <= wlen && k < span && (dec_read4(s_win, wsh + k) & 0xFFFFFFu) == 0xFFFFF4u;
+                    const unsigned long long m = hb_ballot(hit);
+                    if (m) found = (uint32_t)(at - start) + k0 + (uint32_t)__builtin_ctzll(m);
+                }
+            }
+            if (found != RG_INVALID) { start += found; si = start; }
+        }
         if (CODEC == RG_LZ4 && first && r != 0u) {
             // A better first guess than "a token starts at my first byte".  Where literal runs are long, tokens are rare and a parse that
             // starts inside literal bytes may not meet one for the whole region (measured on this library's own streams: the exits
@@ -299,6 +318,14 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 tokstart = (uint32_t)si;
                 SnElem e;
                 if (!sn_parse_uniform(s_win + wsh + rel, n_src - si, e)) { invalid = true; break; }
+                // A literal of more than 64 KiB ends the parse as invalid: the Snappy encoders whose blocks decode unit by unit never write one (they
+                // compress 64 KiB at a time), while a stray parse reads any byte FC..FF as "a literal, its length in the next 3-4 bytes" -- an exit up
+                // to the end of the stream, which the belief rounds (a prefix maximum of the exits) hand to every region in between (measured, 1 GiB
+                // of shuffled floats: ~500 such exits among 16 377 regions, 84 ms of repair and a chain that did not verify; rejecting them only in
+                // the parses that start on a guess was not enough: a re-parse from a belief that is itself a stray exit finds them too).  A stream
+                // that really holds such literals (klauspost's one-block streams) does not verify and goes to the single wavefront -- where its
+                // copies across 64 KiB would have sent it anyway.
+                if (e.lit > 65536u) { invalid = true; break; }
                 p = si + e.hdr;
                 if (e.lit > n_src - p || e.lit > 0xFFFFFFF0ull) { invalid = true; break; }
                 p += e.lit;
@@ -409,6 +436,7 @@ __device__ __forceinline__ bool rg_step_serial(const uint8_t *__restrict__ src, 
                 uint64_t v = 0;
                 for (uint32_t i = 0; i < nb; i++) v |= (uint64_t)src[p + 1u + i] << (8u * i);
                 lit = v + 1u; hdr = 1u + nb;
+                if (lit > 65536u) return false;                          // (as rg_parse_region: no chain through literals of more than 64 KiB)
             }
         } else if (kind == 1u) { hdr = 2; ml = 4u + (x & 7u); }
         else if (kind == 2u) { hdr = 3; ml = 1u + x; }

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(1024) void k_sy_compact(SyPlan *sy, const SyUnit *_
 // and is resumed by the next launch, after k_sy_big has done all posted copies with the whole chip.  The LAST launch copies inline.
 // Unit state between launches (SyUnit): rtp = stream position of the token to resume at, rout = output position there, state bit 0 = unit
 // done, bit 1 = the literal run of the token at rtp was posted (the rest of that sequence is on record and is not parsed again).
-template <bool TOK>
+template <bool TOK, int CODEC = RG_LZ4>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SY_WAVES))) void k_sy_decode(const uint8_t *__restrict__ src, uint64_t n_src, SyUnit *un, const uint32_t *__restrict__ list,
                                                    SyPlan *sy, SyBig *big, uint8_t *D, uint16_t *S, int last, const RgPlan *rg, const RgRegion *reg,
                                                    const uint2 *tok, uint32_t tokcap) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SY_WAVES))) 
         const uint32_t start = cont ? rtp : entry;
         uint32_t out = cont ? RFL(R->rout) : O;        // next output byte
         bool parked;
-        const bool ok = sy_decode_unit<true, SY_PWIN, TOK>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen),
+        const bool ok = sy_decode_unit<true, SY_PWIN, TOK, CODEC>(src, n_src, start, exitp, 0u, O, out, D, S, s_win, s_tq, s_d, s_s, lane, last, rtp, st, R, sy, big, parked, O + RFL(R->outlen),
                                                            TOK ? &ts : nullptr);
         if (!parked) {
             if ((!ok || out != O + RFL(R->outlen)) && lane == 0) atomicExch(&sy->fail, 1u);
@@ -563,7 +563,15 @@ __global__ void k_sy_finish(const RgPlan *rg, const SyPlan *sy, DecPlan *dp, int
 
 // Runs behind k_dec_plan / k_dec_indexed on a block whose index was rebuilt (hb_launch_lz4_region_index): does nothing when that
 // index held; decodes into `dst` otherwise.  `work` = the region workspace, `sym_work` = hb_lz4_sym_workspace(cap) bytes.
-int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_work, int mark_post, hipStream_t s) {
+// a Snappy block (hb_snappy.hip): the plan at a.work is an SnPlan -- same first words -- and the block also has to produce the length it declares
+__global__ void k_sy_finish_sn(const RgPlan *rg, const SyPlan *sy, DecPlan *dp) {
+    if (!sy->go || sy->fail) return;
+    if (rg->total != (uint64_t)dp->nbytes) return;                      // (SnPlan.nbytes: the uvarint; the single wavefront reports the mismatch)
+    dp->mode = DEC_INDEXED; dp->fail = 0;
+}
+
+// codec: RG_LZ4, or RG_SNAPPY (elements; no token store; the chain is hb_launch_snappy_region_chain's)
+int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_work, int mark_post, hipStream_t s, int codec) {
     const RgLayout RL = rg_layout(a.cap);
     uint8_t *w = a.work + 256;
     RgPlan *rg = (RgPlan *)(w + RL.plan);
@@ -587,7 +595,7 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     uint32_t *list = (uint32_t *)(sym_work + L.list);
     hb_prof_begin("k_sy_units", s);
     static const bool no_tok = [] { const char *e = getenv("HIPBLOSC_DEBUG_NO_TOKEN_STORE"); return e && *e && *e != '0'; }();   // A/B (k_rg_parse then wrote none either)
-    const uint2 *tok = no_tok ? nullptr : (const uint2 *)(sym_work + L.tok);
+    const uint2 *tok = (no_tok || codec == RG_SNAPPY) ? nullptr : (const uint2 *)(sym_work + L.tok);
     hipLaunchKernelGGL(k_sy_gate, dim3(1), dim3(1024), 0, s, rg, (const RgRegion *)reg, dp, sy, groups, per, hb_sy_slots(), tok ? 1 : 0);
     hipLaunchKernelGGL(k_sy_units, dim3((nreg + 3) / 4), dim3(64), 0, s, rg, reg, (const uint2 *)(w + RL.trace), sy, un);
     hipLaunchKernelGGL(k_sy_compact, dim3(1), dim3(1024), 0, s, sy, un, list);
@@ -595,7 +603,9 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     for (int k = 0; k < SY_ROUNDS; k++) {
         const int last = k + 1 == SY_ROUNDS;
         hb_prof_begin("k_sy_decode", s);
-        if (tok) hipLaunchKernelGGL(k_sy_decode<true>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
+        if (codec == RG_SNAPPY) hipLaunchKernelGGL((k_sy_decode<false, RG_SNAPPY>), dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
+                                                   (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));
+        else if (tok) hipLaunchKernelGGL(k_sy_decode<true>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
                                     (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));
         else hipLaunchKernelGGL(k_sy_decode<false>, dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
                                 (const RgPlan *)rg, (const RgRegion *)reg, tok, rg_tokcap(rs));      // (HIPBLOSC_DEBUG_NO_TOKEN_STORE: A/B)
@@ -627,7 +637,8 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     uint32_t *itembase = (uint32_t *)(sym_work + L.items);
     hipLaunchKernelGGL(k_sy_items, dim3(1), dim3(1024), 0, s, un, list, sy, itembase);
     hipLaunchKernelGGL(k_sy_resolve, dim3(2048), dim3(512), 0, s, un, list, sy, dst, S, itembase);
-    hipLaunchKernelGGL(k_sy_finish, dim3(1), dim3(1), 0, s, rg, sy, dp, mark_post);
+    if (codec == RG_SNAPPY) hipLaunchKernelGGL(k_sy_finish_sn, dim3(1), dim3(1), 0, s, (const RgPlan *)rg, (const SyPlan *)sy, dp);
+    else hipLaunchKernelGGL(k_sy_finish, dim3(1), dim3(1), 0, s, rg, sy, dp, mark_post);
     hb_prof_end(s);
     HB_HIP_TRY(hipGetLastError());
     return HB_OK;

@@ -314,7 +314,7 @@ int hb_decompress_frames_multi(int nframes, const void *const *frame, const size
                 if (frame[k] && hb_parse_header(frame[k], n[k], &h) == HB_OK && (hb_device_codec(h.codec) || (h.flags & HB_FLAG_MEMCPY)) &&
                     (size_t)h.nbytes <= cap[k] && (size_t)h.cbytes <= n[k]) {
                     max_n = std::max(max_n, std::max<size_t>(h.nbytes, 1));
-                    if (!(h.flags & HB_FLAG_MEMCPY) && h.codec != HB_SNAPPY && h.cbytes >= HB_HEADER_SIZE && hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) &&
+                    if (!(h.flags & HB_FLAG_MEMCPY) && h.cbytes >= HB_HEADER_SIZE && hb_indexless_parallel((size_t)h.cbytes - HB_HEADER_SIZE, h.nbytes) &&
                         n[k] <= (((size_t)h.cbytes + 7) & ~(size_t)7) + 32) qflags = HB_QUEUE_FOREIGN_FRAMES;
                 }
             }

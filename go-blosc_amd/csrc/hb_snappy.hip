@@ -66,65 +66,7 @@ __global__ void k_sn_dec_plan(const uint8_t *__restrict__ src, uint64_t n_src, c
     plan->mode = 1;
 }
 
-// FILL: 64 lanes parse 64 stream bytes "as if an element started at my byte"; the real chain is walked on the scalar side.
-// Elements go to s_tq as {lsrc | lit << 13 | mlen << 22, offset | pos << 16}.  Returns true when it stopped at the end of the
-// slice or at an element the lane-parallel path does not take (literal longer than 511 bytes, 4-byte offset, too close to lim).
-__device__ __forceinline__ bool sn_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq,
-                                        uint2 *s_tq, const int lane) {
-    bool stop = false;
-    while (nq < 64u && !stop) {
-        if (si == lim) { stop = true; break; }
-        const uint32_t base = si, p = base + (uint32_t)lane;
-        const uint32_t w = dec_read4(s_in, sh + p);
-        const uint32_t t = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, kind = t & 3u, x = t >> 2;
-        bool cplx = p >= lim;
-        uint32_t lit = 0, mlen = 0, offv = 0, hdr = 1;
-        if (kind == 0u) {
-            if (x < 60u) lit = x + 1u;
-            else if (x == 60u) { lit = b1 + 1u; hdr = 2u; }
-            else if (x == 61u) { lit = (b1 | (b2 << 8)) + 1u; hdr = 3u; }
-            else cplx = true;
-            if (lit > 511u) cplx = true;
-        } else if (kind == 1u) { mlen = 4u + (x & 7u); offv = ((t >> 5) << 8) | b1; hdr = 2u; }
-        else if (kind == 2u) { mlen = 1u + x; offv = b1 | (b2 << 8); hdr = 3u; }
-        else cplx = true;
-        const uint32_t lsrc = p + hdr, nxt = lsrc + lit;
-        if (nxt > lim) cplx = true;
-        const unsigned long long cmask = hb_ballot(cplx);
-        unsigned long long tmask = 0;
-        uint32_t cur;
-        {
-            const uint32_t nrel = cplx ? 64u : nxt - base;
-            const uint32_t succ = nrel < 64u ? nrel : (uint32_t)lane;
-            uint32_t j = 0, lastj;
-            for (;;) {
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j));
-                const uint32_t j1 = __builtin_amdgcn_readlane(succ, (int)j);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j1));
-                const uint32_t j2 = __builtin_amdgcn_readlane(succ, (int)j1);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j2));
-                const uint32_t j3 = __builtin_amdgcn_readlane(succ, (int)j2);
-                asm volatile("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(j3));
-                j = __builtin_amdgcn_readlane(succ, (int)j3);
-                lastj = j3;
-                if (j == j3) break;
-            }
-            cur = base + __builtin_amdgcn_readlane(nrel, (int)lastj);
-            const unsigned long long cm = tmask & cmask;
-            if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
-        }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-        if ((tmask >> lane) & 1ull) {
-            uint2 e; e.x = lsrc | (lit << 13) | (mlen << 22); e.y = offv | (p << 16);
-            s_tq[nq + rank] = e;
-        }
-        nq += (uint32_t)__builtin_popcountll(tmask);
-        si = cur;
-    }
-    return stop;
-}
-
-// (one element the slow way: sn_parse_uniform, hb_lz4_region.h)
+// (the window parser sn_fill and the one-element parser sn_parse_uniform: hb_lz4_region.h -- the symbolic decoder of foreign blocks walks elements too)
 
 __global__ __launch_bounds__(64) void k_sn_dec_indexed(const uint8_t *__restrict__ src, uint64_t n_src, uint8_t *__restrict__ dst,
                                                        const uint8_t *__restrict__ index, SnPlan *plan) {
@@ -553,14 +495,21 @@ int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
         rg_regions(a.n, &rs, &nreg);
         int rc = hb_launch_snappy_region_chain(a.src, a.n, a.cap, w, &plan->hdr, s);
         if (rc) return rc;
-        HB_HIP_TRY(hipMemsetAsync(units, 0, (nunits + 2) * 4, s));
-        hb_prof_begin("k_snr_units", s);
-        hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units);
-        hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
-        hb_prof_end(s);
-        hb_prof_begin("k_sn_dec_blocks", s);
-        hipLaunchKernelGGL(k_sn_dec_blocks, dim3((unsigned)(nunits < 2048 ? nunits : 2048)), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (const uint32_t *)units, plan);
-        hb_prof_end(s);
+        if (a.sym_work) {
+            // the larger workspace: the symbolic decoder of foreign blocks (hb_lz4_sym.hip) takes the verified chain -- units of a region's size on
+            // every wavefront the chip holds, copies from in front of a unit resolved afterwards; any stream whose offsets fit 16 bits
+            rc = hb_launch_lz4_sym_decode(a, a.dst, a.sym_work, 0, s, RG_SNAPPY);
+            if (rc) return rc;
+        } else {
+            HB_HIP_TRY(hipMemsetAsync(units, 0, (nunits + 2) * 4, s));
+            hb_prof_begin("k_snr_units", s);
+            hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units);
+            hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
+            hb_prof_end(s);
+            hb_prof_begin("k_sn_dec_blocks", s);
+            hipLaunchKernelGGL(k_sn_dec_blocks, dim3((unsigned)(nunits < 2048 ? nunits : 2048)), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (const uint32_t *)units, plan);
+            hb_prof_end(s);
+        }
     }
     if (a.index) {
         const uint64_t units = (a.cap + HB_CHUNK - 1) / HB_CHUNK;

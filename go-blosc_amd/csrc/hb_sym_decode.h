@@ -262,7 +262,7 @@ __device__ __forceinline__ void sy_match_wave(uint8_t *D, uint16_t *S, const uin
 // stream is not what the chain promised (offset 0, offset in front of `base`, a final sequence that announces a match, output past
 // `limit`: nothing is written there).
 // TOK: the stretch is walked region by region of the token discovery and fed from its token store `ts` where that is usable (see below).
-template <bool SYM, uint32_t PWIN = RG_PWIN, bool TOK = false>
+template <bool SYM, uint32_t PWIN = RG_PWIN, bool TOK = false, int CODEC = RG_LZ4>
 __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, const uint64_t n_src, const uint32_t start, const uint32_t exitp, const uint32_t base,
                                                const uint32_t O, uint32_t &out, uint8_t *D, uint16_t *S, uint8_t *s_win, uint2 *s_tq, uint8_t *s_d, uint16_t *s_s,
                                                const int lane, const int last, const uint32_t rtp, const uint32_t st, SyUnit *R, SyPlan *sy, SyBig *big, bool &parked,
@@ -496,7 +496,9 @@ __device__ __forceinline__ bool sy_decode_unit(const uint8_t *__restrict__ src, 
             walk_from = RFL(R->pnext);
             ok = single(rtp, ls, lit, mlen, off, mlen ? 0u : (uint32_t)src[rtp] & 0xF0u);
         }
-        if constexpr (!TOK) {
+        if constexpr (CODEC == RG_SNAPPY) {                            // elements instead of sequences (sn_walk, hb_lz4_region.h); nothing ever parks
+            if (ok && !parked) ok = sn_walk<PWIN>(src, n_src, walk_from, exitp, s_win, s_tq, lane, batch, single);
+        } else if constexpr (!TOK) {
             if (ok && !parked) ok = rg_walk<PWIN>(src, n_src, walk_from, exitp, s_win, s_tq, lane, batch, single);
         } else {
             // Region by region of the token discovery: where a region's first parse left its tokens (from RgRegion.pad0 on they are the chain's, if that

@@ -208,6 +208,72 @@ def test_foreign_snappy_frames_decode_block_parallel(hb, O):
     assert not (hb.lib().hb_last_result_flags() & 1)
 
 
+def test_foreign_snappy_frames_through_both_workspaces(hb, O):
+    """Device-pointer API: with hb_decompress_frame_workspace() an index-less Snappy block is decoded one 64 KiB unit per wavefront (k_sn_dec_blocks;
+    needs an encoder that compresses 64 KiB blocks that share nothing), with hb_decompress_frame_workspace_foreign() by the symbolic decoder
+    (hb_lz4_sym.hip fed with elements: any stream whose offsets fit 16 bits).  A stream with copies ACROSS the 64 KiB units tells them apart:
+    the single wavefront with the small workspace, in parallel with the large one; same bytes every time."""
+    L = hb.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    H2D, D2H = 1, 2
+
+    def dmalloc(nb):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), nb) == 0
+        return ptr
+
+    rng = np.random.default_rng(5)
+    x = O.synth(O.D_F32, (8 << 20) // 4)
+    block_structured = O.compress_frame(x, codec=O.SNAPPY, shuffle=1, typesize=4)
+    # copies that reach 40 000 - 60 000 bytes back, every few dozen bytes: across every 64 KiB boundary, offsets in 16 bits
+    base = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+
+    def lit(b):
+        v = len(b) - 1
+        return (bytes([v << 2]) if v < 60 else bytes([61 << 2, v & 255, v >> 8]) if v < 65536 else bytes([62 << 2, v & 255, (v >> 8) & 255, v >> 16])) + b
+    body = lit(base[:65536]) + lit(base[65536:])
+    want = bytearray(base)
+    while len(want) < (2 << 20):
+        off = int(rng.integers(40000, 60000))
+        ln = int(rng.integers(8, 65))
+        body += bytes([(ln - 1) << 2 | 2]) + struct.pack("<H", off)
+        want += want[len(want) - off: len(want) - off + ln]
+        extra = rng.integers(0, 256, int(rng.integers(1, 30)), dtype=np.uint8).tobytes()
+        body += lit(extra); want += extra
+    n2 = len(want)
+    var = b""
+    v = n2
+    while v >= 128:
+        var += bytes([v & 127 | 128]); v >>= 7
+    var += bytes([v])
+    block = var + body
+    assert O.snappy_decompress(np.frombuffer(block, np.uint8), n2).tobytes() == bytes(want)
+    crossing = np.frombuffer(struct.pack("<BBBBIII", 2, hb.Snappy, 0, 1, n2, n2, 16 + len(block)) + block, np.uint8)
+    for f, raw, flags_small, flags_large in ((block_structured, x.view(np.uint8).reshape(-1), 1, 1), (crossing, np.frombuffer(bytes(want), np.uint8), 0, 1)):
+        n = raw.size
+        small, large = L.hb_decompress_frame_workspace(n), L.hb_decompress_frame_workspace_foreign(n)
+        d_frame, d_out, d_res, d_work = dmalloc(f.size + 64), dmalloc(n), dmalloc(64), dmalloc(large)
+        try:
+            assert hip.hipMemcpy(d_frame, f.ctypes.data, f.size, H2D) == 0
+            for wb, want_flag in ((small, flags_small), (large, flags_large)):
+                assert hip.hipMemset(d_out, 0, n) == 0
+                rc = L.hb_decompress_frame_dev(d_frame, f.size, d_out, n, 0, d_work, wb, d_res, None)
+                assert rc == 0 and hip.hipDeviceSynchronize() == 0
+                res = np.zeros(32, np.uint8)
+                back = np.empty(n, np.uint8)
+                assert hip.hipMemcpy(res.ctypes.data, d_res, 32, D2H) == 0 and hip.hipMemcpy(back.ctypes.data, d_out, n, D2H) == 0
+                assert int(res[:4].view(np.int32)[0]) == 0
+                assert np.array_equal(back, raw)
+                assert int(res[4:8].view(np.uint32)[0]) & 1 == want_flag, (f.size, wb == large)
+        finally:
+            for ptr in (d_frame, d_out, d_res, d_work):
+                hip.hipFree(ptr)
+
+
 def test_snappy_errors_match_the_oracle(hb, O):
     # mutated Snappy frames: the device must report what the restated reference decoder reports (error class, or the same bytes)
     rng = np.random.default_rng(99)
