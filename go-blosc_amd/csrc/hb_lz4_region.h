@@ -134,24 +134,23 @@ __device__ __forceinline__ bool sn_parse_uniform(const uint8_t *p, uint64_t avai
 // Window-parallel element parser for the passes that copy nothing (rg_fill's counterpart): 64 lanes parse 64 stream bytes "as if an element started
 // at my byte", the chain is followed on the scalar side (Snappy windows hold up to 32 elements, but a parse is not the decoder's hot loop).
 // Queue entry: {position (window-relative), output bytes of the element}.  An element whose header does not lie inside the window, or a literal whose
-// length takes three or four bytes, ends the walk (-> sn_parse_uniform).  si may come back beyond lim: a literal's bytes need not be staged.
+// length takes two to four bytes (more than 256 bytes), ends the walk (-> sn_parse_uniform).  si may come back beyond lim: a literal's bytes need not be staged.
 __device__ __forceinline__ bool sn_rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
     bool stop = false;
     while (nq < 64u && !stop) {
         if (si >= lim) { stop = true; break; }
         const uint32_t base = si, p = base + (uint32_t)lane;
         const uint32_t w = dec_read4(s_in, sh + p);
-        const uint32_t t = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, kind = t & 3u, x = t >> 2;
+        const uint32_t t = w & 255u, b1 = (w >> 8) & 255u, kind = t & 3u, x = t >> 2;
         bool cplx = p + 5u > lim;
         uint32_t olen, hdr, lit = 0;
         if (kind == 0u) {
             hdr = 1u; lit = x + 1u;
             if (x == 60u) { lit = b1 + 1u; hdr = 2u; }
-            else if (x == 61u) { lit = (b1 | (b2 << 8)) + 1u; hdr = 3u; }
-            else if (x > 61u) cplx = true;
+            else if (x > 60u) cplx = true;                       // (a literal of more than 256 bytes: one at a time -- the caller has rules about those)
             olen = lit;
         } else if (kind == 1u) { olen = 4u + (x & 7u); hdr = 2u; }
-        else { olen = 1u + x; hdr = kind == 2u ? 3u : 5u; }
+        else { olen = 1u + x; hdr = 3u; if (kind == 3u) cplx = true; }     // (a copy with a 4-byte offset: one at a time -- the caller has rules about those too)
         const uint32_t nrel = cplx ? 64u : (uint32_t)lane + hdr + lit;
         const unsigned long long cmask = hb_ballot(cplx);
         unsigned long long tmask = 0;
