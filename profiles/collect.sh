@@ -19,6 +19,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/reftrace -- python3 $
 cp $(ls $O/reftrace/*/*kernel_stats.csv | head -1) $O/reference_frame_kernel_stats.csv || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/owntrace -- python3 $R/tools/region_debug.py --mib 1024 --dataset f32 --reps 5 --writer device > $O/owntrace.log 2>&1 || true
 cp $(ls $O/owntrace/*/*kernel_stats.csv | head -1) $O/indexless_frame_kernel_stats.csv || true
+# the same data as a foreign Snappy frame (oracle's 64 KiB-block encoder): element discovery (k_snr_*) + symbolic decode, kernel stats of 3 decodes
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/sntrace -- python3 $R/tools/region_debug.py --codec snappy --mib 1024 --dataset f32 --reps 3 > $O/sntrace.log 2>&1 || true
+cp $(ls $O/sntrace/*/*kernel_stats.csv | head -1) $O/snappy_foreign_frame_kernel_stats.csv || true
 # SQ counters of the same reference-written frame's decode (token discovery k_rg_*, symbolic decode k_sy_*): instruction mix, waits, waves
 A="$R/tools/region_debug.py --mib 1024 --dataset f32 --reps 2"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY --output-format csv -d $O/refsq -- python3 $A > $O/refsq.log 2>&1 || true
