@@ -312,6 +312,53 @@ def test_snappy_errors_match_the_oracle(hb, O):
     assert checked == 360
 
 
+def test_mutated_foreign_snappy_frames_on_the_parallel_paths(hb, O):
+    """The same contract as test_snappy_errors_match_the_oracle at a size where a block without an index goes through the element discovery and the
+    parallel decoders (payload >= 256 KiB): whatever a mutation does to the chain -- copies that reach too far, elements that run off the stream, a
+    declared length that no longer fits, literals of megabytes -- the device reports what the restated reference decoder reports, or the same bytes."""
+    rng = np.random.default_rng(1234)
+    by_code = {-1: hb.ErrInvalidData, -2: hb.ErrInvalidHeader, -3: hb.ErrInvalidVersion, -4: hb.ErrInvalidCodec,
+               -5: hb.ErrSizeMismatch, -8: hb.ErrDecompressionFailed}
+    x = np.concatenate([O.synth(O.D_F32, (1 << 20) // 4).view(np.uint8), rng.integers(0, 256, 1 << 19, dtype=np.uint8),
+                        np.frombuffer((b"a foreign snappy frame, mutated. " * 20000)[: 1 << 19], np.uint8)])
+    seeds = [O.compress_frame(x, codec=O.SNAPPY, shuffle=0, typesize=1).tobytes(), O.compress_frame(x, codec=O.SNAPPY, shuffle=1, typesize=4).tobytes()]
+    checked = parallel = 0
+    for f in seeds:
+        cb = hb.ParseHeader(f).NBytesComp
+        assert cb - 16 >= (256 << 10)
+        for trial in range(48):
+            g = bytearray(f)
+            kind = trial % 6
+            if kind == 0:
+                g[int(rng.integers(16, cb))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                pos = int(rng.integers(16, cb))
+                g[pos:pos + 4] = rng.integers(0, 256, min(4, len(g) - pos), dtype=np.uint8).tobytes()
+            elif kind == 2:
+                cut = int(rng.integers(cb // 2, cb))
+                g = g[:cut]; g[12:16] = struct.pack("<I", cut)
+            elif kind == 3:
+                g[4:8] = struct.pack("<I", max(1, int.from_bytes(g[4:8], "little") + int(rng.integers(-50, 50))))
+            elif kind == 4:                                   # a tag that announces a literal of up to 4 GiB / a copy with a 4-byte offset
+                g[int(rng.integers(16 + 8, cb - 8))] = int(rng.choice([0xF8, 0xFC, 0xFF, 0x03, 0xF4]))
+            else:                                             # a stretch of the stream replaced by noise
+                pos = int(rng.integers(16 + 8, cb - 5000))
+                g[pos:pos + 4096] = rng.integers(0, 256, 4096, dtype=np.uint8).tobytes()
+            g = bytes(g)
+            try:
+                want = (None, O.decompress_frame(np.frombuffer(g, np.uint8)).tobytes())
+            except O.OracleError as e:
+                want = (by_code[e.code], None)
+            try:
+                got = (None, hb.Decompress(g))
+                parallel += hb.lib().hb_last_result_flags() & 1
+            except hb.BloscError as e:
+                got = (type(e), None)
+            assert got == want, (trial, kind, got[0], want[0])
+            checked += 1
+    assert checked == 96
+
+
 def test_snappy_forged_index_is_not_trusted(hb, O):
     # a checksum-correct HBSX index with the wrong unit geometry, or with offsets that do not sit on element boundaries, must
     # not change the decoded bytes
