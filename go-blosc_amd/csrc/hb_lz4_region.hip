@@ -70,6 +70,7 @@ __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jo
 // parses region r from its believed first token (reg[r].entry) to the first token at / after the next region's start; one wavefront.
 // first: nothing is on record yet.  s_win: RG_PWIN + 128 bytes, s_tq: DTQ entries, both this wave's own.
 // tok / tokcap: the token store (hb_lz4_region.h), or NULL.
+template <int CODEC> __device__ __forceinline__ bool rg_step_serial(const uint8_t *__restrict__ src, const uint64_t n_src, uint64_t &p, uint64_t &cum);
 template <int CODEC = RG_LZ4>
 __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src, const uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, const uint32_t r,
                                                 const int first, uint8_t *s_win, uint2 *s_tq, const int lane, uint2 *tok = nullptr, const uint32_t tokcap = 0) {
@@ -89,12 +90,13 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
         // parse further up (in periodic data stray and true chains run side by side and never meet: a record overwritten by a
         // stray parse would make the correction that follows one region behind pay a full parse per region too).
         const bool mm = !first && RFL(R->exit0) != RG_INVALID;
-        const uint32_t exit0 = RFL(R->exit0), outlen0 = RFL(R->outlen0);
+        const uint32_t exit0 = RFL(R->exit0), outlen0 = RFL(R->outlen0), rec0 = RFL(R->entry0);     // (rec0: where the recorded parse began -- see the guess rules of the Snappy parser)
         if (!mm) for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
         uint64_t si = start, wpos = 0, out = 0;
         uint32_t wlen = 0, wsh = 0, nq = 0, ntok = 0, exitp = RG_INVALID, lastbk = RG_INVALID;
         uint32_t last_ntok = DEC_BPERM_MIN;                              // (dec_fill_lean: how the previous window's chain was followed)
         uint32_t fat_hold = 0;                                           // windows the fat parser still has
+        uint32_t clean = 0;                                              // (Snappy, a guessed parse) elements since the last one that cannot be on a chain
         bool invalid = false, merged = false;
         uint32_t mpos = 0, mcum = 0, mc0 = 0;
         auto refill = [&](uint64_t at) __attribute__((always_inline)) {
@@ -111,23 +113,62 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
         };
         wave_sync();
         if (CODEC == RG_SNAPPY && first && r != 0u) {
-            // A better first guess than "an element starts at my first byte" where it matters: a block the encoder found nothing in is ONE literal
-            // of 65 536 bytes -- F4 FF FF + the block -- twice a region's length, and a parse that starts inside literal bytes hops through them
-            // (any byte is a tag) and past the next header with them: stray and true chain never meet, every such literal is a hop the belief
-            // rounds make one after the other (measured, the 2-bit plane of 1 GiB of shuffled floats: 2048 of them, 443 ms in k_snr_settle and a
-            // chain that did not verify in time).  The header is easy to spot and the parse starts there.  Only a guess: the chain is verified as a whole.
-            uint32_t found = RG_INVALID;
+            // A better first guess than "an element starts at my first byte" where it matters.  In a stretch the encoder found little in, the chain is
+            // literals of kilobytes -- a whole 64 KiB block as ONE literal, F4 FF FF + the block, where it found nothing -- with a copy here and there, and
+            // a parse that starts inside literal bytes hops through them (any byte is a tag) and past the next header with them: stray and true chain
+            // do not meet, the region's exit is garbage, and the belief rounds repair such stretches region by region (measured, 1 GiB of shuffled
+            // floats: a third of the exits wrong after the first parse, the chain settled by halves over six rounds of re-parses: 4-5 ms; float64 with
+            // three noise planes: 13 ms).  The headers of long literals are easy to tell from noise though: a tag F4 whose chain -- the literal, then
+            // whatever follows it -- runs for 24 elements without meeting one that no 64 KiB-block encoder writes (a copy-4, a literal of more than
+            // 64 KiB, an element that leaves the stream).  Garbage meets one every fourth element: 0.74^24 is one false header in 1400 candidates, and a
+            // region holds ~125 bytes F4.  So: every F4 of the region is a candidate, 64 at a time are followed by a lane each (straight from memory: the
+            // chain leaves the region at once), and the parse starts at the first one that holds.  Only a guess, like the other one: the chain is
+            // verified as a whole.  Where the stream is dense with copies no candidate holds and the parse starts at the region's first byte, as before.
+            uint32_t found = RG_INVALID, ncand = 0;
+            uint32_t *const cl = (uint32_t *)s_tq;                         // candidate positions (DTQ * 2 words: room for 128)
+            auto validate = [&](const uint32_t cnt) __attribute__((always_inline)) {
+                const uint32_t q = (uint32_t)lane < cnt ? cl[lane] : RG_INVALID;
+                bool ok = q != RG_INVALID;
+                uint64_t p = q, cum = 0;
+                uint32_t nlong = 0;                                        // literals of more than 256 bytes on the way
+                for (int i = 0; i < 24; i++) {
+                    const bool go = ok && p < n_src;
+                    if (!hb_ballot(go)) break;
+                    if (go) { const uint64_t p0 = p; ok = rg_step_serial<RG_SNAPPY>(src, n_src, p, cum); if (ok && p - p0 > 259u) nlong++; }
+                }
+                // ... and the chain must be a chain of LITERALS: where the stream is dense with copies everything synchronises -- a stray F4 jumps, lands,
+                // falls onto the chain within a few elements and runs on without a fault (measured: 15 957 of 16 377 regions "found" a header that way
+                // and started in their middle; every one of them had to be parsed again).  Four long literals among the 24 elements: half of a noise
+                // stretch's elements are, next to none of a copy-dense one's.
+                ok = ok && nlong >= 4u;
+                const unsigned long long m = hb_ballot(ok);
+                if (m) found = (uint32_t)__builtin_amdgcn_readlane(q, (int)__builtin_ctzll(m));   // (the list is in stream order)
+            };
             for (uint64_t at = start; at < bnext && found == RG_INVALID; at += RG_PWIN - 64u) {
                 refill(at);
                 const uint32_t span = (uint32_t)((bnext - at) < (uint64_t)wlen ? (bnext - at) : (uint64_t)wlen);
                 for (uint32_t k0 = 0; k0 < span && found == RG_INVALID; k0 += 64u) {
                     const uint32_t k = k0 + (uint32_t)lane;
-                    const bool hit = k + 3u <= wlen && k < span && (dec_read4(s_win, wsh + k) & 0xFFFFFFu) == 0xFFFFF4u;
+                    const bool hit = k < span && s_win[wsh + k] == 0xF4u;
                     const unsigned long long m = hb_ballot(hit);
-                    if (m) found = (uint32_t)(at - start) + k0 + (uint32_t)__builtin_ctzll(m);
+                    if (!m) continue;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (hit) cl[ncand + rank] = (uint32_t)at + k;
+                    ncand += (uint32_t)__builtin_popcountll(m);
+                    if (ncand >= 64u) {
+                        wave_sync();
+                        validate(64u);
+                        const uint32_t rest = cl[64u + (uint32_t)lane];
+                        wave_sync();
+                        ncand -= 64u;
+                        if ((uint32_t)lane < ncand) cl[lane] = rest;
+                    }
                 }
             }
-            if (found != RG_INVALID) { start += found; si = start; }
+            if (found == RG_INVALID && ncand) { wave_sync(); validate(ncand); }
+            wave_sync();
+            if (found != RG_INVALID && found >= start && found < bnext) { start = found; si = start; clean = 1000u; }     // (a header that held: on the chain from the first element)
+            wlen = 0; wpos = 0;                                              // (the window was only the scan's)
         }
         if (CODEC == RG_LZ4 && first && r != 0u) {
             // A better first guess than "a token starts at my first byte".  Where literal runs are long, tokens are rare and a parse that
@@ -270,7 +311,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 const uint32_t pbk = wave_shr1(bk, lastbk);
                 if (mm) {
                     bool hit = false; uint32_t c0 = 0;
-                    if ((uint32_t)lane < cnt && bk != pbk && bk < RG_BUCKETS) { const uint2 o = tr[RG_DENSE + bk]; hit = o.x == (uint32_t)ap; c0 = o.y; }
+                    if ((uint32_t)lane < cnt && bk != pbk && bk < RG_BUCKETS) { const uint2 o = tr[RG_DENSE + bk]; hit = o.x == (uint32_t)ap && o.x >= rec0; c0 = o.y; }
                     const unsigned long long hm = hb_ballot(hit);
                     if (hm) {
                         const int j = __builtin_ctzll(hm);
@@ -288,7 +329,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 }
                 if (cnt) lastbk = (uint32_t)__builtin_amdgcn_readlane(bk, (int)cnt - 1);
                 out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-                ntok += cnt;
+                ntok += cnt; clean += cnt;
                 if (over) { exitp = RFL(__builtin_amdgcn_readlane((uint32_t)ap, (int)__builtin_ctzll(over))); done = true; nq = 0; break; }
                 if (!fat) {
                     const uint16_t rest = ((const uint16_t *)s_tq)[64 + lane < DTQ ? 64 + lane : 0];
@@ -332,10 +373,24 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 const bool guess = first && r != 0u;
                 bool okp = sn_parse_uniform(s_win + wsh + rel, n_src - si, e);
                 if (okp && (e.kind == 3u || e.lit > 65536u || e.lit > n_src - (si + e.hdr))) okp = false;
+                // (c) ... and while a guess has not run 16 elements in a row without such proof, it does not follow a literal of more than 256 bytes either:
+                //     the few elements a stray parse reads before it falls onto the chain hold the tag F4 once in 256, and that jump -- up to two regions
+                //     ahead, landing on the chain -- makes the regions it flies over look empty until the next round takes it back (measured: 2200 of
+                //     16 377).  A real literal passed over that way is hopped through byte by byte and the chain met again behind it.
+                if (okp && guess && clean < 16u && e.lit > 256u) okp = false;
                 if (!okp) {
-                    if (guess) { si += 1u; if (si >= bnext) { exitp = (uint32_t)si; break; } continue; }
+                    if (guess) {
+                        // ... and its RECORD starts over: what the belief rounds merge with must be a parse that follows the rules of every other parse
+                        // from its first token on ("once two parses meet they stay together"), and this one has just broken them.  Dense tokens and the
+                        // token count restart; bucket entries in front of the new start are ignored by whoever reads them (RgRegion.entry0).
+                        si += 1u; clean = 0;
+                        start = (uint32_t)si; out = 0; ntok = 0; lastbk = RG_INVALID;
+                        if (si >= bnext) { exitp = (uint32_t)si; break; }
+                        continue;
+                    }
                     invalid = true; break;
                 }
+                clean++;
                 p = si + e.hdr;
                 p += e.lit;
                 ll = (uint32_t)e.lit; ml = e.mlen;
@@ -371,7 +426,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 if (mm) {
                     if (bk != lastbk && bk < RG_BUCKETS) {
                         const uint32_t ox = RFL(tr[RG_DENSE + bk].x), oy = RFL(tr[RG_DENSE + bk].y);
-                        if (ox == tokstart) { mpos = tokstart; mcum = (uint32_t)out; mc0 = oy; merged = true; break; }
+                        if (ox == tokstart && ox >= rec0) { mpos = tokstart; mcum = (uint32_t)out; mc0 = oy; merged = true; break; }
                     }
                 } else if (lane == 0) {
                     uint2 t; t.x = tokstart; t.y = (uint32_t)out;
@@ -540,7 +595,7 @@ __device__ __forceinline__ void k_rg_settle_body(const uint8_t *__restrict__ src
                 if ((uint64_t)a >= bnext) { s_exit[r] = a; reg[r].outlen = 0; set_need(r, false); }     // no token of the chain starts in this region
                 else {
                     const uint2 *tr = traces + (size_t)r * RG_TRACE;
-                    const uint32_t nt = reg[r].ntrace, exit0 = reg[r].exit0, outlen0 = reg[r].outlen0;
+                    const uint32_t nt = reg[r].ntrace, exit0 = reg[r].exit0, outlen0 = reg[r].outlen0, rec0 = reg[r].entry0;
                     uint64_t p = a, cum = 0;
                     uint32_t ti = 0;
                     bool settled = false;
@@ -551,7 +606,7 @@ __device__ __forceinline__ void k_rg_settle_body(const uint8_t *__restrict__ src
                         while (ti < nt && tr[ti].x < (uint32_t)p) ti++;
                         uint32_t cum0 = RG_INVALID;
                         if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
-                        else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
+                        else if (p >= rb && (uint32_t)p >= rec0) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
                         if (cum0 != RG_INVALID) { s_exit[r] = exit0; reg[r].outlen = (uint32_t)(cum + (outlen0 - cum0)); set_need(r, false); reg[r].pad0 = (uint32_t)p; settled = true; break; }
                         if (!rg_step_serial<CODEC>(src, n_src, p, cum)) break;     // one token, serially
                     }
@@ -649,7 +704,7 @@ __device__ __forceinline__ void k_rg_fix_body(const uint8_t *__restrict__ src, u
     R->entry = a;
     if ((uint64_t)a >= bnext) { R->exit = a; R->outlen = 0; R->needfull = 0; return; }
     const uint2 *tr = traces + (size_t)r * RG_TRACE;
-    const uint32_t nt = R->ntrace, exit0 = R->exit0, outlen0 = R->outlen0;
+    const uint32_t nt = R->ntrace, exit0 = R->exit0, outlen0 = R->outlen0, rec0 = R->entry0;
     uint64_t p = a, cum = 0;
     uint32_t ti = 0;
     for (int iter = 0; iter < RG_WALKCAP && exit0 != RG_INVALID; iter++) {       // (a longer walk is cheaper as a wave-parallel re-parse)
@@ -657,7 +712,7 @@ __device__ __forceinline__ void k_rg_fix_body(const uint8_t *__restrict__ src, u
         while (ti < nt && tr[ti].x < (uint32_t)p) ti++;
         uint32_t cum0 = RG_INVALID;
         if (ti < nt && tr[ti].x == (uint32_t)p) cum0 = tr[ti].y;
-        else if (p >= rb) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
+        else if (p >= rb && (uint32_t)p >= rec0) { const uint32_t bk = ((uint32_t)p - rb) >> bsh; if (bk < RG_BUCKETS && tr[RG_DENSE + bk].x == (uint32_t)p) cum0 = tr[RG_DENSE + bk].y; }
         if (cum0 != RG_INVALID) { R->exit = exit0; R->outlen = (uint32_t)(cum + (outlen0 - cum0)); R->needfull = 0; R->pad0 = (uint32_t)p; return; }
         if (!rg_step_serial<CODEC>(src, n_src, p, cum)) break;
     }
