@@ -135,22 +135,27 @@ __device__ __forceinline__ bool sn_parse_uniform(const uint8_t *p, uint64_t avai
 // at my byte", the chain is followed on the scalar side (Snappy windows hold up to 32 elements, but a parse is not the decoder's hot loop).
 // Queue entry: {position (window-relative), output bytes of the element}.  An element whose header does not lie inside the window, or a literal whose
 // length takes two to four bytes (more than 256 bytes), ends the walk (-> sn_parse_uniform).  si may come back beyond lim: a literal's bytes need not be staged.
-__device__ __forceinline__ bool sn_rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane) {
+// guess: the caller's parse is only a guess (a region's first parse): an element that cannot be on a chain -- a copy-4, a literal whose length takes three
+// or four bytes -- is then a hop of ONE byte, queued with bit 31 of its position set and no output (the caller restarts its record behind it); else such an
+// element ends the walk like a long literal does.
+__device__ __forceinline__ bool sn_rg_fill(const uint8_t *s_in, const uint32_t sh, const uint32_t lim, uint32_t &si, uint32_t &nq, uint2 *s_tq, const int lane, const bool guess = false) {
     bool stop = false;
     while (nq < 64u && !stop) {
         if (si >= lim) { stop = true; break; }
         const uint32_t base = si, p = base + (uint32_t)lane;
         const uint32_t w = dec_read4(s_in, sh + p);
         const uint32_t t = w & 255u, b1 = (w >> 8) & 255u, kind = t & 3u, x = t >> 2;
-        bool cplx = p + 5u > lim;
+        bool cplx = p + 5u > lim, hop = false;
         uint32_t olen, hdr, lit = 0;
         if (kind == 0u) {
             hdr = 1u; lit = x + 1u;
             if (x == 60u) { lit = b1 + 1u; hdr = 2u; }
-            else if (x > 60u) cplx = true;                       // (a literal of more than 256 bytes: one at a time -- the caller has rules about those)
+            else if (x == 61u) cplx = true;                      // (a literal of more than 256 bytes: one at a time -- the caller has rules about those)
+            else if (x > 61u) { if (guess) hop = true; else cplx = true; }
             olen = lit;
         } else if (kind == 1u) { olen = 4u + (x & 7u); hdr = 2u; }
-        else { olen = 1u + x; hdr = 3u; if (kind == 3u) cplx = true; }     // (a copy with a 4-byte offset: one at a time -- the caller has rules about those too)
+        else { olen = 1u + x; hdr = 3u; if (kind == 3u) { if (guess) hop = true; else cplx = true; } }     // (copy-4: the caller has rules about those too)
+        if (hop) { hdr = 1u; lit = 0u; olen = 0u; }
         const uint32_t nrel = cplx ? 64u : (uint32_t)lane + hdr + lit;
         const unsigned long long cmask = hb_ballot(cplx);
         unsigned long long tmask = 0;
@@ -175,7 +180,7 @@ __device__ __forceinline__ bool sn_rg_fill(const uint8_t *s_in, const uint32_t s
             if (cm) { tmask &= ~cm; cur = base + (uint32_t)__builtin_ctzll(cm); stop = true; }
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-        if ((tmask >> lane) & 1ull) { uint2 e; e.x = p; e.y = olen; s_tq[nq + rank] = e; }
+        if ((tmask >> lane) & 1ull) { uint2 e; e.x = p | (hop ? 0x80000000u : 0u); e.y = olen; s_tq[nq + rank] = e; }
         nq += (uint32_t)__builtin_popcountll(tmask);
         si = cur;
         if (si > lim) break;                                     // (the rest of a literal lies behind the window: the caller moves it)

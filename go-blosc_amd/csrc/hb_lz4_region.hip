@@ -63,6 +63,9 @@ __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jo
 #ifndef RG_LEAN_PARSE
 #define RG_LEAN_PARSE 1
 #endif
+#ifndef RG_SN_GIVEUP
+#define RG_SN_GIVEUP 4096u          // one-byte hops after which a guessed Snappy parse gives up (a region inside one 64 KiB literal makes ~2000 and then hands on an exit nobody needs)
+#endif
 #ifndef RG_FAT_HOLD
 #define RG_FAT_HOLD 8u
 #endif
@@ -96,7 +99,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
         uint32_t wlen = 0, wsh = 0, nq = 0, ntok = 0, exitp = RG_INVALID, lastbk = RG_INVALID;
         uint32_t last_ntok = DEC_BPERM_MIN;                              // (dec_fill_lean: how the previous window's chain was followed)
         uint32_t fat_hold = 0;                                           // windows the fat parser still has
-        uint32_t clean = 0;                                              // (Snappy, a guessed parse) elements since the last one that cannot be on a chain
+        uint32_t clean = 0, nevents = 0;                                 // (Snappy, a guessed parse) elements since the last one that cannot be on a chain; how many of those so far
         bool invalid = false, merged = false;
         uint32_t mpos = 0, mcum = 0, mc0 = 0;
         auto refill = [&](uint64_t at) __attribute__((always_inline)) {
@@ -270,7 +273,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             // the launch).  So a longer extension switches to the fat parser, which stays until RG_FAT_HOLD windows in a row met none.
             const bool fat = CODEC != RG_LZ4 || !RG_LEAN_PARSE || fat_hold != 0u;
             bool stop, refat = false;
-            if constexpr (CODEC == RG_SNAPPY) stop = sn_rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);        // (elements: entry = {position, output bytes})
+            if constexpr (CODEC == RG_SNAPPY) stop = sn_rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane, first && r != 0u);        // (elements: entry = {position, output bytes})
             else if (fat) stop = rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
             else stop = dec_fill_lean(s_win, wsh, wlen, wlen, rel, nq, s_tq, lane, last_ntok);
             if (fat_hold) fat_hold--;
@@ -303,11 +306,24 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                 const uint64_t ap = wpos + (e.x & 0xFFFFu);
                 const unsigned long long over = hb_ballot((uint32_t)lane < cntb && ap >= bnext);
                 const uint32_t cnt = over ? (uint32_t)__builtin_ctzll(over) : cntb;
-                const uint32_t olen = (uint32_t)lane < cnt ? (CODEC == RG_SNAPPY ? e.y : lit + mlen) : 0u;
+                uint32_t lo = 0;                                         // first lane of the batch that goes on record
+                if constexpr (CODEC == RG_SNAPPY) {
+                    // one-byte hops of a guess (sn_rg_fill): the record starts over behind the last of them (see the one-element path below for why)
+                    const unsigned long long evm = hb_ballot((uint32_t)lane < cnt && (e.x >> 31) != 0u);
+                    if (evm) {
+                        const int last = 63 - __builtin_clzll(evm);
+                        nevents += (uint32_t)__builtin_popcountll(evm);
+                        if (nevents >= RG_SN_GIVEUP) { invalid = true; done = true; nq = 0; break; }
+                        lo = (uint32_t)last + 1u;
+                        start = RFL(__builtin_amdgcn_readlane((uint32_t)ap, last)) + 1u; out = 0; ntok = 0; lastbk = RG_INVALID; clean = 0;
+                    }
+                }
+                const bool mine = (uint32_t)lane >= lo && (uint32_t)lane < cnt;
+                const uint32_t olen = mine ? (CODEC == RG_SNAPPY ? e.y : lit + mlen) : 0u;
                 const uint32_t incl = wave_incl_scan_dpp(olen);
-                const uint32_t idx = ntok + (uint32_t)lane;
+                const uint32_t idx = ntok + (uint32_t)lane - lo;
                 // trace: the first RG_DENSE tokens, and the first token that starts in each bucket of the region's stream range
-                const uint32_t bk = (uint32_t)lane < cnt ? ((uint32_t)ap - rb) >> bsh : RG_INVALID;
+                const uint32_t bk = mine ? ((uint32_t)ap - rb) >> bsh : RG_INVALID;
                 const uint32_t pbk = wave_shr1(bk, lastbk);
                 if (mm) {
                     bool hit = false; uint32_t c0 = 0;
@@ -321,15 +337,15 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                         merged = true; done = true; nq = 0;
                         break;
                     }
-                } else if ((uint32_t)lane < cnt) {
+                } else if (mine) {
                     uint2 t; t.x = (uint32_t)ap; t.y = (uint32_t)(out + incl - olen);
                     if (idx < RG_DENSE) tr[idx] = t;
                     if (bk != pbk && bk < RG_BUCKETS) tr[RG_DENSE + bk] = t;
                     if (tk && idx < tokcap) { uint2 k; k.x = (uint32_t)ap; k.y = e.y; tk[idx] = k; }
                 }
-                if (cnt) lastbk = (uint32_t)__builtin_amdgcn_readlane(bk, (int)cnt - 1);
+                if (cnt > lo) lastbk = (uint32_t)__builtin_amdgcn_readlane(bk, (int)cnt - 1);
                 out += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-                ntok += cnt; clean += cnt;
+                ntok += cnt - lo; clean += cnt - lo;
                 if (over) { exitp = RFL(__builtin_amdgcn_readlane((uint32_t)ap, (int)__builtin_ctzll(over))); done = true; nq = 0; break; }
                 if (!fat) {
                     const uint16_t rest = ((const uint16_t *)s_tq)[64 + lane < DTQ ? 64 + lane : 0];
@@ -383,6 +399,10 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                         // ... and its RECORD starts over: what the belief rounds merge with must be a parse that follows the rules of every other parse
                         // from its first token on ("once two parses meet they stay together"), and this one has just broken them.  Dense tokens and the
                         // token count restart; bucket entries in front of the new start are ignored by whoever reads them (RgRegion.entry0).
+                        // A guess that has broken them 64 times is inside literal bytes (one element in four of noise is impossible; a region inside a 64 KiB
+                        // literal would grind through 2000 of these one-element steps: measured, the first parse 1.6 -> 3.9 ms): it gives up -- no exit is
+                        // better than a wrong one, and the belief rounds hand such a region the exit of the literal it lies in.
+                        if (++nevents >= RG_SN_GIVEUP) { invalid = true; break; }
                         si += 1u; clean = 0;
                         start = (uint32_t)si; out = 0; ntok = 0; lastbk = RG_INVALID;
                         if (si >= bnext) { exitp = (uint32_t)si; break; }
