@@ -222,9 +222,11 @@ func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 	// An LZ4 block is one serial chain.  With the restart index the device decodes it chunk-parallel; without one it
 	// first finds and verifies the token chain itself (payloads from 256 KiB, or from 16 KiB when they decode to 2 MiB and more: csrc/hb_lz4_region.hip) and then either
 	// rebuilds the index (frames this library wrote) or decodes symbolically (frames the CPU path wrote, hb_lz4_sym.hip):
-	// ~100 / ~240 GB/s device-resident at 1 GiB.  Below that size -- and for Snappy frames of other writers -- only ONE
-	// wavefront can work on it (~0.15-0.4 GB/s, measured), slower than the pure-Go decoder: those stay on the CPU
-	// unless the caller insists.
+	// ~100 / ~240 GB/s device-resident at 1 GiB.  Below that size only ONE wavefront can work on it (~0.15-0.4 GB/s, measured),
+	// slower than the pure-Go decoder: those stay on the CPU unless the caller insists.  Snappy frames of other writers stay there
+	// too: the device decodes them in parallel when their encoder compressed 64 KiB blocks (golang/snappy, libsnappy: hb_snappy.hip,
+	// 74-109 GB/s at 1 GiB), but what this package's own CPU path writes (klauspost's one-block streams) may hold 4-byte offsets, which
+	// leave the block to one wavefront -- and a frame does not say who wrote it.  ForceDeviceDecode sends them anyway.
 	payload := int(h.NBytesComp) - HeaderSize
 	parallel := hasRestartIndex(data, h) || (Codec(h.VersionLZ) != Snappy && (payload >= 256<<10 || (payload >= 16<<10 && h.NBytesOrig >= 2<<20)))
 	if !h.IsMemcpy() && !parallel && !ForceDeviceDecode {
