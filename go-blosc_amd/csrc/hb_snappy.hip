@@ -356,7 +356,7 @@ __device__ __forceinline__ bool snr_walk(const uint8_t *__restrict__ src, const 
 }
 
 // units[u] = 1 + stream position of the element that starts at output position u * SNB_UNIT (0: none); an element that crosses such a position: fail
-__global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *rgplan, const RgRegion *__restrict__ reg, uint32_t *__restrict__ units) {
+__global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *rgplan, const RgRegion *__restrict__ reg, uint32_t *__restrict__ units, uint32_t nunits_max) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     const int lane = threadIdx.x;
@@ -369,7 +369,8 @@ __global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ sr
         bool bad = false;
         const bool through = snr_walk(src, n_src, entry, exitp, opos, s_win, s_tq, lane, [&](uint32_t cnt, uint64_t pos, uint32_t olen, uint64_t o) __attribute__((always_inline)) {
             if ((uint32_t)lane < cnt && olen) {
-                if ((o & (SNB_UNIT - 1u)) == 0u) units[o / SNB_UNIT] = (uint32_t)pos + 1u;
+                if (o / SNB_UNIT >= (uint64_t)nunits_max) bad = true;         // (more output than the chain's verified total allows: the table ends here)
+                else if ((o & (SNB_UNIT - 1u)) == 0u) units[o / SNB_UNIT] = (uint32_t)pos + 1u;
                 else if ((o / SNB_UNIT) != ((o + olen - 1u) / SNB_UNIT)) bad = true;
             }
         });
@@ -503,7 +504,7 @@ int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
         } else {
             HB_HIP_TRY(hipMemsetAsync(units, 0, (nunits + 2) * 4, s));
             hb_prof_begin("k_snr_units", s);
-            hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units);
+            hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units, (uint32_t)nunits);
             hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
             hb_prof_end(s);
             hb_prof_begin("k_sn_dec_blocks", s);
