@@ -131,6 +131,10 @@ def test_device_decodes_foreign_snappy_frames(hb, O):
         for shuffle, ts in MODES[:3]:
             f = O.compress_frame(x, codec=O.SNAPPY, shuffle=shuffle, typesize=ts).tobytes()
             assert hb.Decompress(f) == xb, (name, shuffle, ts)
+            h = hb.GetInfo(f)
+            payload = h.NBytesComp - 16
+            if not h.IsMemcpy() and (payload >= (256 << 10) or (payload >= (16 << 10) and len(xb) >= (2 << 20))):
+                assert hb.lib().hb_last_result_flags() & 1, (name, shuffle, ts, "a foreign Snappy block of this size decodes in parallel")
         if sn is not None and len(xb) > 20:
             cap = sn.snappy_max_compressed_length(len(xb))
             b = ctypes.create_string_buffer(cap)
