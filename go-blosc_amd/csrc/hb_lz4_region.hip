@@ -63,6 +63,9 @@ __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jo
 #ifndef RG_LEAN_PARSE
 #define RG_LEAN_PARSE 1
 #endif
+#ifndef RG_HEADPARSE
+#define RG_HEADPARSE 0xFFFFFFFFu     // a spotted token further into its region than this is a checkpoint of the parse from the first byte, not its start (OFF: see below)
+#endif
 #ifndef RG_SN_GIVEUP
 #define RG_SN_GIVEUP 4096u          // one-byte hops after which a guessed Snappy parse gives up (a region inside one 64 KiB literal makes ~2000 and then hands on an exit nobody needs)
 #endif
@@ -99,6 +102,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
         uint32_t wlen = 0, wsh = 0, nq = 0, ntok = 0, exitp = RG_INVALID, lastbk = RG_INVALID;
         uint32_t last_ntok = DEC_BPERM_MIN;                              // (dec_fill_lean: how the previous window's chain was followed)
         uint32_t fat_hold = 0;                                           // windows the fat parser still has
+        uint32_t checkpoint = RG_INVALID;                                // (LZ4, first parse) a spotted token the parse from the first byte has to land on
         uint32_t clean = 0, nevents = 0;                                 // (Snappy, a guessed parse) elements since the last one that cannot be on a chain; how many of those so far
         bool invalid = false, merged = false;
         uint32_t mpos = 0, mcum = 0, mc0 = 0;
@@ -258,7 +262,17 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             }
             // (parsing from the first byte as well and keeping that parse when it comes by the spotted token was measured: the dense
             // regions that miss it pay twice, +2 ms per GiB; starting at the token costs the fix round 0.4 ms instead)
-            if (found != RG_INVALID && (uint64_t)start + found < bnext) { start += found; si = start; }
+            if (found != RG_INVALID && (uint64_t)start + found < bnext) {
+                // A token spotted DEEP in the region costs two serial walks of the head in front of it later on, everybody else idle (the reference-written
+                // headline frame: the sequence with the 256 MiB literal run sits 24 KB into its region behind 6000 dense tokens -- 0.42 ms in the re-parse
+                // behind k_rg_fix).  -DRG_HEADPARSE=2048 parses that head HERE, from the region's first byte, with the spotted token as a checkpoint (a
+                // parse that is on the chain by then lands on it and the record is one piece; one that passes over it starts over at the token).
+                // Measured in round 4 and left OFF: the reference-written frame 7.88 -> 7.62 ms (k_rg_fix 0.42 -> 0.12, k_rg_parse +0.13), but this
+                // library's own frames lose -- their deep tokens sit behind literal bytes, the head parse passes over them and is wasted: D-f32
+                // k_rg_parse 1.28 -> 1.44 ms, D-f64 0.69 -> 0.77 and its fix round 0.24 -> 0.43.
+                if (found > RG_HEADPARSE) checkpoint = start + found;
+                else { start += found; si = start; }
+            }
         }
         for (;;) {
             if (si >= bnext) { exitp = (uint32_t)si; break; }           // (si <= n_src always; bnext <= n_src)
@@ -272,7 +286,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             // is a latency chain of window passes per token (measured with lean alone: 8.5 ms instead of 1.2 -- 40 such regions of 16 384 are
             // the launch).  So a longer extension switches to the fat parser, which stays until RG_FAT_HOLD windows in a row met none.
             const bool fat = CODEC != RG_LZ4 || !RG_LEAN_PARSE || fat_hold != 0u;
-            bool stop, refat = false;
+            bool stop, refat = false, recp = false;
             if constexpr (CODEC == RG_SNAPPY) stop = sn_rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane, first && r != 0u);        // (elements: entry = {position, output bytes})
             else if (fat) stop = rg_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
             else stop = dec_fill_lean(s_win, wsh, wlen, wlen, rel, nq, s_tq, lane, last_ntok);
@@ -318,6 +332,14 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
                         start = RFL(__builtin_amdgcn_readlane((uint32_t)ap, last)) + 1u; out = 0; ntok = 0; lastbk = RG_INVALID; clean = 0;
                     }
                 }
+                if (CODEC == RG_LZ4 && checkpoint != RG_INVALID) {
+                    const unsigned long long ge = hb_ballot((uint32_t)lane < cntb && (uint32_t)ap >= checkpoint);
+                    if (ge) {
+                        const int j = __builtin_ctzll(ge);
+                        if (RFL(__builtin_amdgcn_readlane((uint32_t)ap, j)) == checkpoint) checkpoint = RG_INVALID;       // landed on it: one record
+                        else { rel = checkpoint - (uint32_t)wpos; recp = true; nq = 0; break; }                              // passed over it: start over there
+                    }
+                }
                 const bool mine = (uint32_t)lane >= lo && (uint32_t)lane < cnt;
                 const uint32_t olen = mine ? (CODEC == RG_SNAPPY ? e.y : lit + mlen) : 0u;
                 const uint32_t incl = wave_incl_scan_dpp(olen);
@@ -359,6 +381,12 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             }
             if (done) break;
             if (refat) { si = wpos + rel; continue; }
+            if (recp || (CODEC == RG_LZ4 && checkpoint != RG_INVALID && wpos + rel > checkpoint)) {
+                // the record starts over at the spotted token (bucket entries in front of it are ignored by their readers: RgRegion.entry0)
+                si = checkpoint; start = checkpoint; checkpoint = RG_INVALID;
+                out = 0; ntok = 0; lastbk = RG_INVALID; nq = 0;
+                continue;
+            }
             const bool moved = (wpos + rel) != si;
             si = wpos + rel;
             if (CODEC == RG_SNAPPY && si > n_src) { invalid = true; break; }     // (a literal that runs off the stream: a stray parse, or a corrupt block)
@@ -418,6 +446,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             if (si < wpos || si >= wpos + wlen) refill(si);
             rel = (uint32_t)(si - wpos);
             tokstart = (uint32_t)si;
+            if (checkpoint != RG_INVALID && tokstart == checkpoint) checkpoint = RG_INVALID;      // (landed on the spotted token)
             const uint32_t tok = RFL((uint32_t)s_win[wsh + rel]);
             rel++;
             ll = tok >> 4;
