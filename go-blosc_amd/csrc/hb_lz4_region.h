@@ -271,8 +271,26 @@ __device__ __forceinline__ bool sn_walk(const uint8_t *__restrict__ src, const u
         while (nq >= 64u || (all && nq > 0u)) {
             const uint32_t cntb = nq < 64u ? nq : 64u;
             const uint2 e = s_tq[lane];                                    // {lsrc | lit << 13 | mlen << 22, offset | pos << 16}, window-relative (sn_fill)
-            const uint32_t lw = e.x & 0x1FFFu, lit = (e.x >> 13) & 0x1FFu, mlen = e.x >> 22, tw = e.y >> 16;
+            const uint32_t lw = e.x & 0x1FFFu, lit = (e.x >> 13) & 0x1FFu, tw = e.y >> 16;
+            uint32_t mlen = e.x >> 22;
             const uint32_t off = mlen ? (e.y & 0xFFFFu) : 1u;
+            // A Snappy copy ends at 64 bytes, so a run of KiB is dozens of copies at the same distance, each reading what the one before wrote: 64
+            // dependency rounds per batch for the decoder behind this walk (measured, a float ramp at ratio 0.05: pass A 9.1 ms).  Copies that follow
+            // each other at the same distance ARE one copy (out[p + k] = out[p + k - off] for k over both): the first of such a stretch takes the
+            // whole length, the others become empty tokens.
+            {
+                const bool cp = (uint32_t)lane < cntb && mlen != 0u;                    // (a copy element: no literals)
+                const uint32_t poff = wave_shr1(off, 0u);
+                const bool pcp = wave_shr1((uint32_t)cp, 0u) != 0u;
+                const bool cont = cp && pcp && lane != 0 && off == poff;            // continues the copy in the lane before
+                const unsigned long long heads = ~hb_ballot(cont);                  // lanes that start a token of their own
+                const uint32_t incl = wave_incl_scan_dpp(cp ? mlen : 0u);
+                const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
+                const uint32_t endl = above ? (uint32_t)lane + (uint32_t)__builtin_ctzll(above) : 63u;      // last lane of my stretch
+                const uint32_t incl_end = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(endl << 2), (int)incl);
+                if (cont) mlen = 0u;
+                else if (cp) mlen = incl_end - (incl - mlen);
+            }
             const uint2 rest = s_tq[64 + lane < DTQ ? 64 + lane : 0];
             if (!batch(cntb, (uint32_t)wpos + tw, (uint32_t)wpos + lw, lit, mlen, off, wsh + lw)) return false;
             nq -= cntb;
