@@ -136,7 +136,9 @@ __device__ __forceinline__ void dec_match_copy(uint8_t *s_out, uint32_t md, uint
 // fields are parsed here, by 64 lanes that all hold a real token -- the window parser then spends its instructions on finding the chain,
 // not on parsing 64 "as if" tokens of which a dozen are real.  A token whose length extension is longer than one byte is not decoded:
 // like a sequence that passes the end of the unit it rewinds to the one-sequence-at-a-time path.
-template <bool LEAN = false>
+// MERGE (the Snappy decoders): queued copies that follow each other at the same distance, no literals in between, are decoded as ONE copy -- a Snappy copy
+// ends at 64 bytes, a run of KiB is dozens of them, each waiting for the one before (out[p + k] = out[p + k - off] over all of them is the same bytes).
+template <bool LEAN = false, bool MERGE = false>
 __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, uint8_t *s_out, const uint32_t outlen, const uint32_t hist,
                                           uint32_t &di, uint32_t &si, uint32_t &nq, uint2 *s_tq, const bool stop,
                                           bool &rewound, const int lane) {
@@ -161,6 +163,19 @@ __device__ __forceinline__ bool dec_drain(const uint8_t *in, const int inoff, ui
             const uint2 e = s_tq[lane];
             lsrc = (uint32_t)((int)(e.x & 0x1FFFu) + inoff); lit = (e.x >> 13) & 0x1FFu; mlen = e.x >> 22;
             offv = e.y & 0xFFFFu; tp = e.y >> 16;
+            if constexpr (MERGE) {
+                const bool cp = (uint32_t)lane < cntb && mlen != 0u && lit == 0u;
+                const uint32_t poff = wave_shr1(offv, 0u);
+                const bool pcp = wave_shr1((uint32_t)((uint32_t)lane < cntb && mlen != 0u), 0u) != 0u;      // (the lane before ends in a copy, literals in front of it or not)
+                const bool cont = cp && pcp && lane != 0 && offv == poff;
+                const unsigned long long heads = ~hb_ballot(cont);
+                const uint32_t incl = dec_incl_scan(((uint32_t)lane < cntb && mlen != 0u) ? mlen : 0u, lane);
+                const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
+                const uint32_t endl = above ? (uint32_t)lane + (uint32_t)__builtin_ctzll(above) : 63u;
+                const uint32_t incl_end = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(endl << 2), (int)incl);
+                if (cont) mlen = 0u;
+                else if ((uint32_t)lane < cntb && mlen != 0u) mlen = incl_end - (incl - mlen);
+            }
         }
         const uint32_t olen = (uint32_t)lane < cntb ? lit + mlen : 0u;
         const uint32_t incl = dec_incl_scan(olen, lane);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void k_sn_dec_indexed(const uint8_t *__restrict
         while (ok && !done) {
             const bool stop = sn_fill(s_in, sh, slen, si, nq, s_tq, lane);
             bool rewound = false;
-            ok = dec_drain(s_in, (int)sh, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
+            ok = dec_drain<false, true>(s_in, (int)sh, s_out, outlen, 0u, di, si, nq, s_tq, stop, rewound, lane);
             if (!ok || rewound) { ok = false; break; }            // an element that passes the end of the unit: not ours to decide
             if (stop) {
                 if (si == slen) { done = true; break; }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void k_sn_dec_serial(const uint8_t *__restrict_
         const bool stop = sn_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
         bool rewound = false;
         const uint32_t di0 = di;
-        const bool dok = dec_drain(s_win + wsh, 0, out, room, hist, di, rel, nq, s_tq, true, rewound, lane);
+        const bool dok = dec_drain<false, true>(s_win + wsh, 0, out, room, hist, di, rel, nq, s_tq, true, rewound, lane);
         const bool moved = (wpos + rel) != si;
         if (!dok) {
             // a copy that reaches beyond the LDS history (> 64 KiB back) or is malformed: decided one element at a time below,
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64) void k_sn_dec_blocks(const uint8_t *__restrict_
             uint32_t rel = (uint32_t)(si - wpos);
             const bool stop = sn_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
             bool rewound = false;
-            const bool dok = dec_drain(s_win + wsh, 0, s_img, outlen, 0u, di, rel, nq, s_tq, true, rewound, lane);
+            const bool dok = dec_drain<false, true>(s_win + wsh, 0, s_img, outlen, 0u, di, rel, nq, s_tq, true, rewound, lane);
             if (!dok || rewound) { ok = false; break; }             // a copy from in front of the unit, or an element that passes its end: not ours to decide
             const bool moved = (wpos + rel) != si;
             si = wpos + rel;
