@@ -108,7 +108,7 @@ __global__ __launch_bounds__(1024) void k_sy_gate(const RgPlan *rg, const RgRegi
                                                   int have_tok) {
     __shared__ uint32_t s_n[16];
     const int t = threadIdx.x;
-    const uint32_t go = (rg->ok && !(dp->mode == DEC_INDEXED && !dp->fail)) ? 1u : 0u;
+    const uint32_t go = (rg->ok && !(dp->mode != DEC_SERIAL && !dp->fail)) ? 1u : 0u;      // (a Snappy block's plan: mode 2 = its 64 KiB units held, hb_snappy.hip)
     uint32_t n = 0;
     if (go) for (uint32_t r = t; r < rg->nreg; r += 1024u) n += reg[r].outlen != 0u ? 1u : 0u;
     for (int d = 32; d; d >>= 1) n += (uint32_t)__shfl_down((int)n, d);

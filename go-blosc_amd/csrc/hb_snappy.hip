@@ -24,6 +24,9 @@
 #include "hb_lz4.h"
 #include "hb_dec_common.h"
 #include "hb_lz4_region.h"
+#define SY_IMG   2048u          // (the unit decoder of hb_sym_decode.h as hb_lz4_sym.hip configures it: 2 KiB image, 512 bytes of history)
+#define SY_HIST  512u
+#include "hb_sym_decode.h"
 
 struct SnPlan {
     uint32_t mode;        // 0 = serial, 1 = indexed (4 KiB units, stored index), 2 = blocks (64 KiB units found by the discovery)
@@ -290,12 +293,11 @@ __global__ __launch_bounds__(64) void k_sn_dec_serial(const uint8_t *__restrict_
 // block and the remaining literals are emitted at its end), so the element stream is a concatenation of sub-streams that decode to exactly 64 KiB
 // each and copy only from themselves -- but nothing in the stream says where they begin.  The token discovery of hb_lz4_region.hip finds and
 // VERIFIES the element chain (same kernels, element parser: hb_launch_snappy_region_chain); k_snr_units walks it once more with output positions
-// and notes the element that starts at every multiple of 64 KiB of output; k_sn_dec_blocks decodes one such unit per wavefront (64 KiB image in
+// and notes the element that starts at every multiple of 64 KiB of output; k_sn_dec_units decodes one such unit per wavefront (at first with a 64 KiB image in
 // LDS).  Nothing is assumed: a unit must consume exactly its slice, produce exactly its bytes, and no copy may reach in front of it -- an encoder
 // that matches across 64 KiB (klauspost's s2.EncodeSnappy on one large block does) fails that test, and the single wavefront decodes the block.
 // ------------------------------------------------------------------------------------------------------------
 #define SNB_UNIT 65536u
-#define SNB_WIN  4096u
 
 // the verified chain of region r, elements 64 at a time: f(cnt, pos, olen, opos) -- lane < cnt holds the element at stream position pos that
 // produces olen bytes at output position opos (64-bit); returns false when the walk leaves the stream (cannot happen on a verified chain)
@@ -389,88 +391,31 @@ __global__ void k_snr_gate(const RgPlan *__restrict__ rgplan, SnPlan *plan, uint
     plan->mode = 2;
 }
 
-__global__ __launch_bounds__(64) void k_sn_dec_blocks(const uint8_t *__restrict__ src, uint64_t n_src, uint8_t *__restrict__ dst, const uint32_t *__restrict__ units, SnPlan *plan) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[SNB_WIN + 128];
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[SNB_UNIT + 1024];
+// One 64 KiB unit per wavefront with the unit decoder of the symbolic pass, without the symbols (hb_sym_decode.h, sy_decode_unit<false>: a 2 KiB image in
+// LDS, older sources fetched from the output in HBM, all lanes at once) fed by sn_walk: 5 KiB of LDS per wavefront -- 16 per CU.  (Round 4's first
+// version kept the whole unit in a 64 KiB LDS image: two wavefronts per CU, 16.5 ms for 1 GiB where this one takes ~5.)  `base` = the unit's first
+// byte: a copy from in front of it is not this decoder's to resolve and fails the unit, as does a unit that does not produce exactly its bytes.
+#define SNU_PWIN 2048u
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_sn_dec_units(const uint8_t *__restrict__ src, uint64_t n_src, uint8_t *__restrict__ dst,
+                                                                                              const uint32_t *__restrict__ units, SnPlan *plan) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[SNU_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
+    __shared__ __attribute__((aligned(16))) uint8_t s_d[SY_IMG + 64];
     if (plan->mode != 2) return;
     const int lane = threadIdx.x;
     const uint32_t nunits = plan->nunits, nbytes = plan->nbytes;
     for (uint32_t u = blockIdx.x; u < nunits; u += gridDim.x) {
         const uint32_t a0 = RFL(units[u]), a1 = RFL(units[u + 1]);
-        const uint64_t d0 = (uint64_t)u * SNB_UNIT;
-        const uint32_t outlen = (uint32_t)(((uint64_t)nbytes - d0) < (uint64_t)SNB_UNIT ? ((uint64_t)nbytes - d0) : (uint64_t)SNB_UNIT);
+        const uint32_t O = u * SNB_UNIT;                                  // (nbytes < 2^32: so is every unit's start)
+        const uint32_t limit = nbytes - O < SNB_UNIT ? nbytes : O + SNB_UNIT;
         bool ok = a0 != 0u && a1 != 0u && a0 < a1 && (uint64_t)(a1 - 1u) <= n_src;
-        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); continue; }
-        const uint64_t s0 = a0 - 1u, s1 = a1 - 1u;
-        uint64_t si = s0, wpos = 0;
-        uint32_t wlen = 0, wsh = 0, nq = 0, di = 0;
-        auto refill = [&](uint64_t at) __attribute__((always_inline)) {     // the window never reaches beyond the unit's slice
-            const uint8_t *g = src + at;
-            wsh = (uint32_t)((uintptr_t)g & 15u);
-            const uint64_t left = s1 - at;
-            wlen = (uint32_t)(left < (uint64_t)(SNB_WIN - 16u) ? left : (uint64_t)(SNB_WIN - 16u));
-            const u32x4 *ga = (const u32x4 *)(g - wsh);
-            const uint32_t nv = (wsh + wlen + 15u) >> 4;
-            wave_sync();
-            for (uint32_t i = lane; i < nv; i += 64) ((u32x4 *)s_win)[i] = ga[i];
-            wpos = at;
-            wave_sync();
-        };
-        wave_sync();
-        while (ok && si < s1) {
-            if (si < wpos || si - wpos + 1024u > wlen) { if (si != wpos || wlen == 0) refill(si); }
-            uint32_t rel = (uint32_t)(si - wpos);
-            const bool stop = sn_fill(s_win, wsh, wlen, rel, nq, s_tq, lane);
-            bool rewound = false;
-            const bool dok = dec_drain<false, true>(s_win + wsh, 0, s_img, outlen, 0u, di, rel, nq, s_tq, true, rewound, lane);
-            if (!dok || rewound) { ok = false; break; }             // a copy from in front of the unit, or an element that passes its end: not ours to decide
-            const bool moved = (wpos + rel) != si;
-            si = wpos + rel;
-            if (moved && !stop) continue;
-            if (si >= s1) break;
-            if (moved && si - wpos + 1024u > wlen && wpos + wlen < s1) continue;      // stopped at the window edge: refill first
-            // one element the slow way: a literal longer than 511 bytes, a copy with a 4-byte offset
-            if (si < wpos || si + 8u > wpos + wlen) refill(si);
-            rel = (uint32_t)(si - wpos);
-            SnElem e;
-            if (!sn_parse_uniform(s_win + wsh + rel, s1 - si, e)) { ok = false; break; }
-            si += e.hdr;
-            if (e.kind == 0u) {
-                if (e.lit > s1 - si || e.lit > (uint64_t)(outlen - di)) { ok = false; break; }
-                const uint32_t take = (uint32_t)e.lit;
-                const uint8_t *g = src + si;
-                uint32_t k0 = 0;
-                for (; k0 + 4096u <= take; k0 += 4096u) {                // 4 x 16 B per lane in flight
-                    u32x4 v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) v[q] = ld16u(g + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) ((hb_u128u *)(s_img + di + k0 + (uint32_t)q * 1024u + (uint32_t)lane * 16u))->v = v[q];
-                }
-                for (uint32_t k = k0 + lane; k < take; k += 64) s_img[di + k] = g[k];
-                si += take; di += take;
-                wave_sync();
-            } else {
-                if (e.off == 0 || e.off > (uint64_t)di || e.mlen > outlen - di) { ok = false; break; }
-                wave_sync();
-                dec_match_copy(s_img, di, (uint32_t)e.off, e.mlen, lane);
-                di += e.mlen;
-                wave_sync();
-            }
+        uint32_t out = O;
+        if (ok) {
+            bool parked;
+            ok = sy_decode_unit<false, SNU_PWIN, false, RG_SNAPPY>(src, n_src, a0 - 1u, a1 - 1u, O, O, out, dst, nullptr, s_win, s_tq, s_d, nullptr,
+                                                                   lane, 1, 0u, 0u, nullptr, nullptr, nullptr, parked, limit);
         }
-        if (ok) ok = (si == s1) && (di == outlen) && nq == 0u;
-        if (!ok) { if (lane == 0) atomicExch(&plan->fail, 1u); wave_sync(); continue; }
-        wave_sync();
-        uint8_t *o = dst + d0;                                          // flush the unit image: 16-byte stores on an aligned body
-        uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u);
-        if (head > outlen) head = outlen;
-        if ((uint32_t)lane < head) o[lane] = s_img[lane];
-        const uint32_t body = (outlen - head) >> 4;
-        if (head == 0) { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + i * 16u) = *(const u32x4 *)(s_img + i * 16u); }
-        else { for (uint32_t i = lane; i < body; i += 64) *(u32x4 *)(o + head + i * 16u) = ((const hb_u128u *)(s_img + head + i * 16u))->v; }
-        const uint32_t done_b = head + body * 16u;
-        if (done_b + lane < outlen) o[done_b + lane] = s_img[done_b + lane];
+        if (!ok || out != limit) { if (lane == 0) atomicExch(&plan->fail, 1u); }
         wave_sync();
     }
 }
@@ -496,20 +441,20 @@ int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
         rg_regions(a.n, &rs, &nreg);
         int rc = hb_launch_snappy_region_chain(a.src, a.n, a.cap, w, &plan->hdr, s);
         if (rc) return rc;
+        // units first: an encoder that compresses 64 KiB at a time (every Snappy encoder in wide use) leaves units that share nothing ...
+        HB_HIP_TRY(hipMemsetAsync(units, 0, (nunits + 2) * 4, s));
+        hb_prof_begin("k_snr_units", s);
+        hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units, (uint32_t)nunits);
+        hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
+        hb_prof_end(s);
+        hb_prof_begin("k_sn_dec_units", s);
+        hipLaunchKernelGGL(k_sn_dec_units, dim3((unsigned)(nunits < 16384 ? nunits : 16384)), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (const uint32_t *)units, plan);
+        hb_prof_end(s);
         if (a.sym_work) {
-            // the larger workspace: the symbolic decoder of foreign blocks (hb_lz4_sym.hip) takes the verified chain -- units of a region's size on
-            // every wavefront the chip holds, copies from in front of a unit resolved afterwards; any stream whose offsets fit 16 bits
+            // ... and with the larger workspace a stream whose copies do cross them (or whose elements straddle them) still decodes in parallel: the
+            // symbolic decoder of foreign blocks (hb_lz4_sym.hip) takes the verified chain -- any stream whose offsets fit 16 bits; idle when the units held
             rc = hb_launch_lz4_sym_decode(a, a.dst, a.sym_work, 0, s, RG_SNAPPY);
             if (rc) return rc;
-        } else {
-            HB_HIP_TRY(hipMemsetAsync(units, 0, (nunits + 2) * 4, s));
-            hb_prof_begin("k_snr_units", s);
-            hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units, (uint32_t)nunits);
-            hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
-            hb_prof_end(s);
-            hb_prof_begin("k_sn_dec_blocks", s);
-            hipLaunchKernelGGL(k_sn_dec_blocks, dim3((unsigned)(nunits < 2048 ? nunits : 2048)), dim3(64), 0, s, a.src, (uint64_t)a.n, a.dst, (const uint32_t *)units, plan);
-            hb_prof_end(s);
         }
     }
     if (a.index) {
