@@ -160,7 +160,7 @@ def test_device_decodes_foreign_snappy_frames(hb, O):
 def test_foreign_snappy_frames_decode_block_parallel(hb, O):
     """VERDICT r2/r3 item 7 (codec.go:236-244): a Snappy block that comes without this library's unit index -- written by another encoder; here the
     oracle's, which like golang/snappy and libsnappy compresses 64 KiB blocks that share nothing -- goes through the element discovery
-    (hb_lz4_region.hip with the element parser) and is decoded one 64 KiB unit per wavefront (k_sn_dec_blocks): flags & 1.  A stream whose
+    (hb_lz4_region.hip with the element parser) and is decoded one 64 KiB unit per wavefront (k_sn_dec_units): flags & 1.  A stream whose
     copies cross those units (what klauspost's s2.EncodeSnappy writes for one large block) must come out right too: the single wavefront."""
     rng = np.random.default_rng(77)
     n = 12 << 20
@@ -213,9 +213,9 @@ def test_foreign_snappy_frames_decode_block_parallel(hb, O):
 
 
 def test_foreign_snappy_frames_through_both_workspaces(hb, O):
-    """Device-pointer API: with hb_decompress_frame_workspace() an index-less Snappy block is decoded one 64 KiB unit per wavefront (k_sn_dec_blocks;
-    needs an encoder that compresses 64 KiB blocks that share nothing), with hb_decompress_frame_workspace_foreign() by the symbolic decoder
-    (hb_lz4_sym.hip fed with elements: any stream whose offsets fit 16 bits).  A stream with copies ACROSS the 64 KiB units tells them apart:
+    """Device-pointer API: with either workspace an index-less Snappy block is decoded one 64 KiB unit per wavefront (k_sn_dec_units; needs an encoder
+    that compresses 64 KiB blocks that share nothing); hb_decompress_frame_workspace_foreign() adds the symbolic decoder behind it (hb_lz4_sym.hip fed
+    with elements: any stream whose offsets fit 16 bits).  A stream with copies ACROSS the 64 KiB units tells them apart:
     the single wavefront with the small workspace, in parallel with the large one; same bytes every time."""
     L = hb.lib()
     hip = ctypes.CDLL("libamdhip64.so")

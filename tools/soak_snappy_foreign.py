@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """soak: composite data x filters as FOREIGN Snappy frames (the oracle's 64 KiB-block encoder, no unit index) through the element discovery and the
-parallel decoders (symbolic decoder via the host API; k_sn_dec_blocks via the device API with the small workspace is tests/test_gpu_f3.py's);
+parallel decoders (k_sn_dec_units, the symbolic decoder behind it; both workspaces through the device API: tests/test_gpu_f3.py);
 device bytes == input, and how many decoded in parallel"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
