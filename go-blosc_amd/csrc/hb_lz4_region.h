@@ -131,6 +131,54 @@ __device__ __forceinline__ bool sn_parse_uniform(const uint8_t *p, uint64_t avai
     else { if (avail < 5) return false; e.mlen = 1u + x; e.off = byte(1) | (byte(2) << 8) | (byte(3) << 16) | (byte(4) << 24); e.hdr = 5; }
     return true;
 }
+// one token (LZ4 sequence / Snappy element) at stream position p, by one lane: p moves behind it, cum grows by its output bytes; false: it runs off
+// the stream or is malformed (the caller then asks for a wave-parallel parse, which decides)
+template <int CODEC>
+__device__ __forceinline__ bool rg_step_serial(const uint8_t *__restrict__ src, const uint64_t n_src, uint64_t &p, uint64_t &cum) {
+    if constexpr (CODEC == RG_SNAPPY) {
+        if (p >= n_src) return false;
+        // (the tag and the next three bytes in one read where the stream has them: one memory round trip per element for the walks that go lane by lane)
+        const bool wide = n_src - p >= 4u;
+        const uint32_t w = wide ? ld4u(src + p) : (uint32_t)src[p];
+        const uint32_t t = w & 255u, kind = t & 3u, x = t >> 2;
+        uint64_t hdr = 1, lit = 0, ml = 0;
+        if (kind == 0u) {
+            if (x < 60u) lit = x + 1u;
+            else {
+                const uint32_t nb = x - 59u;
+                if (n_src - p < 1u + nb) return false;
+                uint64_t v = 0;
+                if (wide && nb <= 3u) v = (w >> 8) & (nb == 1u ? 0xFFu : nb == 2u ? 0xFFFFu : 0xFFFFFFu);
+                else for (uint32_t i = 0; i < nb; i++) v |= (uint64_t)src[p + 1u + i] << (8u * i);
+                lit = v + 1u; hdr = 1u + nb;
+                if (lit > 65536u) return false;                          // (as rg_parse_region: no chain through literals of more than 64 KiB)
+            }
+        } else if (kind == 1u) { hdr = 2; ml = 4u + (x & 7u); }
+        else if (kind == 2u) { hdr = 3; ml = 1u + x; }
+        else return false;                                           // (copy-4: as rg_parse_region, no chain through one)
+        if (n_src - p < hdr || lit > n_src - p - hdr) return false;
+        p += hdr + lit; cum += lit + ml;
+        return true;
+    } else {
+        const uint32_t tok = src[p];
+        uint64_t q = p + 1, ll = tok >> 4;
+        bool bad = false;
+        if (ll == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ll += x; if (x != 255u) break; } }
+        if (bad || ll > n_src - q) return false;
+        q += ll;
+        uint64_t ml = 0;
+        if (q != n_src) {
+            if (n_src - q < 2) return false;
+            q += 2; ml = (tok & 15u) + 4u;
+            if ((tok & 15u) == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ml += x; if (x != 255u) break; } }
+            if (bad) return false;
+        }
+        cum += ll + ml;
+        p = q;
+        return true;
+    }
+}
+
 // Window-parallel element parser for the passes that copy nothing (rg_fill's counterpart): 64 lanes parse 64 stream bytes "as if an element started
 // at my byte", the chain is followed on the scalar side (Snappy windows hold up to 32 elements, but a parse is not the decoder's hot loop).
 // Queue entry: {position (window-relative), output bytes of the element}.  An element whose header does not lie inside the window, or a literal whose

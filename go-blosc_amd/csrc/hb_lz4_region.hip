@@ -76,7 +76,6 @@ __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jo
 // parses region r from its believed first token (reg[r].entry) to the first token at / after the next region's start; one wavefront.
 // first: nothing is on record yet.  s_win: RG_PWIN + 128 bytes, s_tq: DTQ entries, both this wave's own.
 // tok / tokcap: the token store (hb_lz4_region.h), or NULL.
-template <int CODEC> __device__ __forceinline__ bool rg_step_serial(const uint8_t *__restrict__ src, const uint64_t n_src, uint64_t &p, uint64_t &cum);
 template <int CODEC = RG_LZ4>
 __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src, const uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, const uint32_t r,
                                                 const int first, uint8_t *s_win, uint2 *s_tq, const int lane, uint2 *tok = nullptr, const uint32_t tokcap = 0) {
@@ -532,50 +531,6 @@ __device__ __forceinline__ void k_rg_parse_body(const uint8_t *__restrict__ src,
 __global__ __launch_bounds__(64) void k_rg_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first, uint2 *tok, uint32_t tokcap) { k_rg_parse_body(src, n_src, plan, reg, traces, first, tok, tokcap, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(64) void k_snr_parse(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *plan, RgRegion *reg, uint2 *traces, int first) { k_rg_parse_body<RG_SNAPPY>(src, n_src, plan, reg, traces, first, nullptr, 0u, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(64) void k_rg_parse_b(const RgJob *__restrict__ jobs, int first) { const RgJob j = jobs[blockIdx.y]; k_rg_parse_body(j.src, j.n_src, j.plan, j.reg, j.traces, first, j.tok, j.tokcap, blockIdx.x, gridDim.x); }
-
-// one token (LZ4 sequence / Snappy element) at stream position p, by one lane: p moves behind it, cum grows by its output bytes; false: it runs off
-// the stream or is malformed (the caller then asks for a wave-parallel parse, which decides)
-template <int CODEC>
-__device__ __forceinline__ bool rg_step_serial(const uint8_t *__restrict__ src, const uint64_t n_src, uint64_t &p, uint64_t &cum) {
-    if constexpr (CODEC == RG_SNAPPY) {
-        if (p >= n_src) return false;
-        const uint32_t t = src[p], kind = t & 3u, x = t >> 2;
-        uint64_t hdr = 1, lit = 0, ml = 0;
-        if (kind == 0u) {
-            if (x < 60u) lit = x + 1u;
-            else {
-                const uint32_t nb = x - 59u;
-                if (n_src - p < 1u + nb) return false;
-                uint64_t v = 0;
-                for (uint32_t i = 0; i < nb; i++) v |= (uint64_t)src[p + 1u + i] << (8u * i);
-                lit = v + 1u; hdr = 1u + nb;
-                if (lit > 65536u) return false;                          // (as rg_parse_region: no chain through literals of more than 64 KiB)
-            }
-        } else if (kind == 1u) { hdr = 2; ml = 4u + (x & 7u); }
-        else if (kind == 2u) { hdr = 3; ml = 1u + x; }
-        else return false;                                           // (copy-4: as rg_parse_region, no chain through one)
-        if (n_src - p < hdr || lit > n_src - p - hdr) return false;
-        p += hdr + lit; cum += lit + ml;
-        return true;
-    } else {
-        const uint32_t tok = src[p];
-        uint64_t q = p + 1, ll = tok >> 4;
-        bool bad = false;
-        if (ll == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ll += x; if (x != 255u) break; } }
-        if (bad || ll > n_src - q) return false;
-        q += ll;
-        uint64_t ml = 0;
-        if (q != n_src) {
-            if (n_src - q < 2) return false;
-            q += 2; ml = (tok & 15u) + 4u;
-            if ((tok & 15u) == 15u) { int kk = 0; for (;; kk++) { if (q >= n_src || kk > 2048) { bad = true; break; } const uint32_t x = src[q++]; ml += x; if (x != 255u) break; } }
-            if (bad) return false;
-        }
-        cum += ll + ml;
-        p = q;
-        return true;
-    }
-}
 
 // ---- (1b) settle the chain.  Belief of every region about its first token: the furthest position any predecessor's parse reaches (an
 // exclusive prefix maximum of the exits).  On the true chain exits are monotone, so this is the predecessor's exit; a token that

@@ -358,7 +358,8 @@ __device__ __forceinline__ bool snr_walk(const uint8_t *__restrict__ src, const 
 }
 
 // units[u] = 1 + stream position of the element that starts at output position u * SNB_UNIT (0: none); an element that crosses such a position: fail
-__global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *rgplan, const RgRegion *__restrict__ reg, uint32_t *__restrict__ units, uint32_t nunits_max) {
+__global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *rgplan, const RgRegion *__restrict__ reg, uint32_t *__restrict__ units, uint32_t nunits_max,
+                                                  const uint32_t *__restrict__ done) {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[RG_PWIN + 128];
     __shared__ __attribute__((aligned(16))) uint2 s_tq[DTQ];
     const int lane = threadIdx.x;
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ sr
     for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
         const uint32_t entry = RFL(reg[r].entry), exitp = RFL(reg[r].exit);
         if (entry >= exitp) continue;                                    // no element of the chain starts in this region
+        if (done && RFL(done[r]) != 0u) continue;                         // k_snr_units_fast found this region's units from its records
         const uint64_t opos = reg[r].opos;
         bool bad = false;
         const bool through = snr_walk(src, n_src, entry, exitp, opos, s_win, s_tq, lane, [&](uint32_t cnt, uint64_t pos, uint32_t olen, uint64_t o) __attribute__((always_inline)) {
@@ -378,6 +380,92 @@ __global__ __launch_bounds__(64) void k_snr_units(const uint8_t *__restrict__ sr
         });
         if (hb_ballot(bad) || !through) { if (lane == 0) atomicExch(&rgplan->fail, 1u); }
         wave_sync();
+    }
+}
+
+// The same from the discovery's records, without a walk of the whole stream (the wave walk above costs 1.2 ms per GiB only to find 16 384 elements).  A
+// region's first parse left {position, output so far} of the first element in each of 128 slices of its stream range (`traces`, hb_lz4_region.h), and
+// from RgRegion.pad0 on that record lies on the verified chain when the recorded parse ends where the chain does: an element at recorded output c
+// then starts at output opos + outlen - (outlen0 - c).  One wavefront per region, a LANE per record: the lane whose stretch of output -- from its
+// record to the next one's -- holds a multiple of 64 KiB walks the elements from its record (a few dozen, straight from memory) and notes the one that
+// starts there, or finds that an element crosses it (no units: rgplan->fail).  Lane 0 also takes the head, from the region's entry to the first
+// usable record.  A region whose records are not usable, or whose walk would be long, stays with the wave walk (done[r] = 0).
+#define SNU_WALKCAP 256u           // elements a lane walks before it leaves the region to the wave walk (a lane's element costs a memory round trip, the wave's a sixtieth)
+__global__ __launch_bounds__(64) void k_snr_units_fast(const uint8_t *__restrict__ src, uint64_t n_src, RgPlan *rgplan, const RgRegion *__restrict__ reg, const uint2 *__restrict__ traces,
+                                                       uint32_t *__restrict__ units, uint32_t nunits_max, uint32_t *__restrict__ done) {
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    if (lane == 0) done[r] = 0u;
+    if (!rgplan->ok || r >= rgplan->nreg) return;
+    const uint32_t entry = RFL(reg[r].entry), exitp = RFL(reg[r].exit), outlen = RFL(reg[r].outlen);
+    if (entry >= exitp || outlen == 0u) { if (lane == 0) done[r] = 1u; return; }
+    const uint64_t opos = reg[r].opos, oend = opos + outlen;
+    if (((opos + SNB_UNIT - 1u) & ~(uint64_t)(SNB_UNIT - 1u)) >= oend) { if (lane == 0) done[r] = 1u; return; }      // no multiple of 64 KiB in this region's output
+    const uint32_t pad0 = RFL(reg[r].pad0), exit0 = RFL(reg[r].exit0), outlen0 = RFL(reg[r].outlen0), rec0 = RFL(reg[r].entry0);
+    if (pad0 == RG_INVALID || exit0 != exitp || pad0 >= exitp) return;      // records unusable: the wave walk
+    const uint2 *tr = traces + (size_t)r * RG_TRACE + RG_DENSE;
+    // my two records (slices lane and lane + 64), as {position, absolute output}
+    uint32_t x[2]; uint64_t fo[2]; bool v[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint2 t = tr[lane + 64 * q];
+        x[q] = t.x;
+        v[q] = t.x != RG_INVALID && t.x >= pad0 && t.x >= rec0 && t.x < exitp && t.y <= outlen0 && (uint64_t)(outlen0 - t.y) <= (uint64_t)outlen;
+        fo[q] = oend - (uint64_t)(outlen0 - (v[q] ? t.y : 0u));
+    }
+    const unsigned long long V0 = hb_ballot(v[0]), V1 = hb_ballot(v[1]);
+    // where each stretch ends: the next usable record's output (records are in stream order: slice k before slice k + 1), or the region's end
+    auto next_fo = [&](const int q) __attribute__((always_inline)) -> uint64_t {
+        unsigned long long a = q == 0 ? (lane < 63 ? V0 >> (lane + 1) : 0ull) : 0ull;
+        int src_lane, src_q;
+        if (q == 0 && a) { src_lane = lane + 1 + __builtin_ctzll(a); src_q = 0; }
+        else {
+            const unsigned long long b = q == 0 ? V1 : (lane < 63 ? V1 >> (lane + 1) : 0ull);
+            if (!b) { src_lane = -1; src_q = 0; }
+            else { src_lane = (q == 0 ? 0 : lane + 1) + __builtin_ctzll(b); src_q = 1; }
+        }
+        // (every lane takes part in the shuffles)
+        const uint32_t lo0 = (uint32_t)__shfl((int)(uint32_t)fo[0], src_lane < 0 ? 0 : src_lane), hi0 = (uint32_t)__shfl((int)(uint32_t)(fo[0] >> 32), src_lane < 0 ? 0 : src_lane);
+        const uint32_t lo1 = (uint32_t)__shfl((int)(uint32_t)fo[1], src_lane < 0 ? 0 : src_lane), hi1 = (uint32_t)__shfl((int)(uint32_t)(fo[1] >> 32), src_lane < 0 ? 0 : src_lane);
+        if (src_lane < 0) return oend;
+        return src_q == 0 ? (((uint64_t)hi0 << 32) | lo0) : (((uint64_t)hi1 << 32) | lo1);
+    };
+    const uint64_t e0 = next_fo(0), e1 = next_fo(1);
+    // the head: from the region's entry to the first usable record (lane 0's extra stretch)
+    const bool anyv = (V0 | V1) != 0ull;
+    uint64_t hend = oend;
+    {
+        int fl = V0 ? __builtin_ctzll(V0) : (V1 ? __builtin_ctzll(V1) : 0);
+        const uint32_t lo0 = (uint32_t)__shfl((int)(uint32_t)fo[0], fl), hi0 = (uint32_t)__shfl((int)(uint32_t)(fo[0] >> 32), fl);
+        const uint32_t lo1 = (uint32_t)__shfl((int)(uint32_t)fo[1], fl), hi1 = (uint32_t)__shfl((int)(uint32_t)(fo[1] >> 32), fl);
+        if (anyv) hend = V0 ? (((uint64_t)hi0 << 32) | lo0) : (((uint64_t)hi1 << 32) | lo1);
+    }
+    bool bad = false, capped = false;
+    auto stretch = [&](uint64_t p, uint64_t o, const uint64_t oe) __attribute__((always_inline)) {
+        // elements from stream position p (output position o) while they start in front of oe: note those that start on a multiple of 64 KiB
+        uint64_t B = (o + SNB_UNIT - 1u) & ~(uint64_t)(SNB_UNIT - 1u);
+        uint32_t steps = 0;
+        while (B < oe && !bad && !capped) {
+            if (o == B) {
+                if (B / SNB_UNIT >= (uint64_t)nunits_max) { bad = true; break; }
+                units[B / SNB_UNIT] = (uint32_t)p + 1u;
+                B += SNB_UNIT;
+                continue;
+            }
+            if (o > B) { bad = true; break; }                             // an element crossed it
+            if (++steps > SNU_WALKCAP) { capped = true; break; }
+            uint64_t cum = 0;
+            if (!rg_step_serial<RG_SNAPPY>(src, n_src, p, cum)) { bad = true; break; }
+            o += cum;
+        }
+    };
+    if (lane == 0 && hend > opos) stretch(entry, opos, hend);
+#pragma unroll
+    for (int q = 0; q < 2; q++) if (v[q]) stretch(x[q], fo[q], q == 0 ? e0 : e1);
+    const bool anybad = hb_ballot(bad) != 0ull, anycap = hb_ballot(capped) != 0ull;
+    if (lane == 0) {
+        if (anybad) atomicExch(&rgplan->fail, 1u);
+        done[r] = (anybad || !anycap) ? 1u : 0u;                          // (capped: the wave walk does this region again -- same entries)
     }
 }
 
@@ -444,7 +532,12 @@ int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
         // units first: an encoder that compresses 64 KiB at a time (every Snappy encoder in wide use) leaves units that share nothing ...
         HB_HIP_TRY(hipMemsetAsync(units, 0, (nunits + 2) * 4, s));
         hb_prof_begin("k_snr_units", s);
-        hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units, (uint32_t)nunits);
+        static const bool slow_units = [] { const char *e = getenv("HIPBLOSC_DEBUG_SLOW_UNITS"); return e && *e && *e != '0'; }();   // A/B: the wave walk only
+        uint32_t *done = (uint32_t *)(w + L.pmax);                          // (k_rg_pmax / k_snr_fix are through with it)
+        // (regions of a few KiB -- highly compressed blocks -- are walked faster by their wavefront than lane by lane: measured on a float ramp at ratio 0.05)
+        const bool fast_units = !slow_units && rs >= 12288u;
+        if (fast_units) hipLaunchKernelGGL(k_snr_units_fast, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, (const uint2 *)(w + L.trace), units, (uint32_t)nunits, done);
+        hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units, (uint32_t)nunits, fast_units ? (const uint32_t *)done : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
         hb_prof_end(s);
         hb_prof_begin("k_sn_dec_units", s);
