@@ -1147,9 +1147,13 @@ int hb_launch_snappy_region_chain(const uint8_t *src, size_t n, size_t cap, uint
     static const int stop_at = [] { const char *e = getenv("HIPBLOSC_DEBUG_SNR_STOP"); return e && *e ? atoi(e) : 1000; }();   // lab: leave the chain as it is after this many stages
     if (stop_at < 1) return HB_OK;
     hb_prof_begin("k_snr_settle", s);
-    hipLaunchKernelGGL(k_rg_pmax, dim3(1), dim3(1024), 0, s, plan, reg, pmax);
-    hipLaunchKernelGGL(k_snr_fix, dim3((nreg + 63) / 64), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, (const uint32_t *)pmax);
-    hipLaunchKernelGGL(k_snr_parse, dim3(nreg), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, 0);
+    // two chip-wide belief rounds (a lane per region: ~65 us each) before the one-workgroup rounds (0.2 ms while many regions still move)
+    for (int k = 0; k < 2; k++) {
+        hipLaunchKernelGGL(k_rg_pmax, dim3(1), dim3(1024), 0, s, plan, reg, pmax);
+        hipLaunchKernelGGL(k_snr_fix, dim3((nreg + 63) / 64), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, (const uint32_t *)pmax);
+        hipLaunchKernelGGL(k_snr_parse, dim3(nreg), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, 0);
+        if (stop_at < 2) break;
+    }
     for (int k = 0; k < RG_FIXROUNDS && k + 2 <= stop_at; k++) {
         hipLaunchKernelGGL(k_snr_settle<false>, dim3(1), dim3(1024), 0, s, src, (uint64_t)n, plan, reg, traces);
         hipLaunchKernelGGL(k_snr_parse, dim3(nreg), dim3(64), 0, s, src, (uint64_t)n, plan, reg, traces, 0);     // (a workgroup per region: those that wait for a parse wait for nothing else)
