@@ -19,8 +19,11 @@
 //       copied one per lane by the machinery shared with the LZ4 decoder (hb_dec_common.h: a literal element is a token without
 //       a match, a copy a token without literals).  The index is not trusted: a unit must consume exactly its slice and
 //       produce exactly its 4 KiB, and no copy may reach before the unit; anything else raises a flag ...
-//   k_sn_dec_serial  : ... and the whole block is decoded by one wavefront front to back (also: blocks without an index, e.g.
-//       written by the reference): 64 KiB of history in LDS, copies that reach further back read the output in HBM.
+//   k_sn_dec_serial  : ... and the whole block is decoded by one wavefront front to back: 64 KiB of history in LDS, copies that reach
+//       further back read the output in HBM.  Also the authority for every block the parallel paths do not vouch for.
+//   blocks WITHOUT an index (any other writer's; round 4, further down): the element chain is found and verified by the token discovery of
+//       hb_lz4_region.hip (k_snr_*), cut at every 64 KiB of output (k_snr_units_fast / k_snr_units) and decoded one unit per wavefront
+//       (k_sn_dec_units); the symbolic decoder of hb_lz4_sym.hip behind it for streams whose copies cross those units (larger workspace).
 #include "hb_lz4.h"
 #include "hb_dec_common.h"
 #include "hb_lz4_region.h"

@@ -167,7 +167,9 @@ size_t  hb_decompress_frame_workspace(size_t n_out);
  * not written chunk-locally (what the reference's lz4.CompressBlock writes, codec.go:63-75) is decoded in parallel as well
  * (symbolic decode from the verified token chain: ~2 bytes per output byte); with the smaller workspace such a frame goes to one
  * wavefront.  It also holds the token store of the discovery (~2.7 bytes per stream byte), with which the index of a frame of THIS
- * library that carries none is rebuilt without a second walk (decode ~6 % faster).  The host-pointer entry points pick the size themselves. */
+ * library that carries none is rebuilt without a second walk (decode ~6 % faster).  A Snappy frame without the unit index decodes in parallel
+ * with either workspace when its encoder compressed 64 KiB blocks that share nothing (golang/snappy, libsnappy); the larger one adds the symbolic
+ * decoder for streams whose copies cross those blocks (offsets in 16 bits).  The host-pointer entry points pick the size themselves. */
 size_t  hb_decompress_frame_workspace_foreign(size_t n_out);
 int hb_compress_frame_dev(const void *d_src, size_t n, void *d_frame, size_t cap,
                           int codec, int level, int shuffle, int typesize, unsigned opts,
