@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--typesize", type=int, default=4)
     ap.add_argument("--writer", default="oracle", choices=["oracle", "device"],
                     help="oracle: the restated reference encoder (64 KiB window); device: this library WITHOUT the index trailer")
-    ap.add_argument("--codec", default="lz4", choices=["lz4", "snappy"], help="snappy: the oracle's Snappy encoder (64 KiB blocks) -> element discovery + k_sn_dec_blocks")
+    ap.add_argument("--codec", default="lz4", choices=["lz4", "snappy"], help="snappy: the oracle's Snappy encoder (64 KiB blocks) -> element discovery + k_sn_dec_units")
     ap.add_argument("--small-work", action="store_true", help="workspace without the symbolic decoder's scratch (foreign frames then decode on one wavefront)")
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--dump", default="", help="lo:hi -- print the final state of these regions")
