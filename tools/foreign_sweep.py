@@ -22,19 +22,24 @@ def main():
     ap.add_argument("--mib", type=int, default=1024)
     ap.add_argument("--datasets", default="f64,i32,ramp,rand")
     ap.add_argument("--shuffles", default="1,2")
+    ap.add_argument("--codec", default="lz4", choices=["lz4", "snappy"], help="snappy: the oracle's Snappy encoder / this library's Snappy frames without the unit index")
     a = ap.parse_args()
     for ds in a.datasets.split(","):
         for sh in a.shuffles.split(","):
             for w in ("oracle", "device"):
-                cmd = [sys.executable, os.path.join(ROOT, "tools", "region_debug.py"), "--mib", str(a.mib), "--reps", "2", "--dataset", ds,
-                       "--shuffle", sh, "--typesize", "8" if ds == "f64" else "4", "--writer", w]
+                cmd = [sys.executable, os.path.join(ROOT, "tools", "region_debug.py"), "--mib", str(a.mib), "--reps", "4", "--dataset", ds,
+                       "--shuffle", sh, "--typesize", "8" if ds == "f64" else "4", "--writer", w, "--codec", a.codec]
                 t = subprocess.run(cmd, capture_output=True, text=True).stdout      # (a child per frame: a fresh workspace each time)
-                m = re.search(r"rep 1: ([0-9.]+) ms.*= ([0-9.]+) GB/s", t)
+                # the best of the reps behind the first (a frame's decode right after another process has returned gigabytes of device memory has been seen to
+                # take 100+ ms once, wall clock, with every stage at its usual time: the driver's business, not the decoder's)
+                reps = [(float(a_), float(b_)) for a_, b_ in re.findall(r"rep [1-9]: ([0-9.]+) ms.*= ([0-9.]+) GB/s", t)]
+                m = min(reps) if reps else None
                 st = re.search(r"stage ms (\{.*\})", t)
                 fl = re.search(r"flags (\d+)", t)
                 s = ast.literal_eval(st.group(1)) if st else {}
-                print(f"{ds} sh{sh} {w}: {m.group(1) if m else '?'} ms {m.group(2) if m else '?'} GB/s flags {fl.group(1) if fl else '?'} "
-                      f"settle {s.get('k_rg_settle')} serial {s.get('k_dec_serial')} sy_decode {s.get('k_sy_decode')} big {s.get('k_sy_big')}", flush=True)
+                print(f"{ds} sh{sh} {w}: {m[0] if m else '?'} ms {m[1] if m else '?'} GB/s flags {fl.group(1) if fl else '?'} "
+                      f"settle {s.get('k_rg_settle', s.get('k_snr_settle'))} serial {s.get('k_dec_serial', s.get('k_sn_dec_serial'))} sy_decode {s.get('k_sy_decode')} "
+                      f"big {s.get('k_sy_big')} units {s.get('k_sn_dec_units')}", flush=True)
 
 
 if __name__ == "__main__":
