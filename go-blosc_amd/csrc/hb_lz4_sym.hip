@@ -600,7 +600,7 @@ int hb_launch_lz4_sym_decode(const hb_dec_args &a, uint8_t *dst, uint8_t *sym_wo
     hipLaunchKernelGGL(k_sy_units, dim3((nreg + 3) / 4), dim3(64), 0, s, rg, reg, (const uint2 *)(w + RL.trace), sy, un);
     hipLaunchKernelGGL(k_sy_compact, dim3(1), dim3(1024), 0, s, sy, un, list);
     hb_prof_end(s);
-    for (int k = 0; k < SY_ROUNDS; k++) {
+    for (int k = codec == RG_SNAPPY ? SY_ROUNDS - 1 : 0; k < SY_ROUNDS; k++) {       // (Snappy: nothing parks -- no element reaches SY_BIG -- so one launch, the last)
         const int last = k + 1 == SY_ROUNDS;
         hb_prof_begin("k_sy_decode", s);
         if (codec == RG_SNAPPY) hipLaunchKernelGGL((k_sy_decode<false, RG_SNAPPY>), dim3(nunits < 16384u ? nunits : 16384u), dim3(64), 0, s, a.src, (uint64_t)a.n, un, list, sy, big, dst, S, last,
