@@ -540,7 +540,9 @@ int hb_launch_snappy_decode(const hb_dec_args &a, hipStream_t s) {
         // (regions of a few KiB -- highly compressed blocks -- are walked faster by their wavefront than lane by lane: measured on a float ramp at ratio 0.05)
         const bool fast_units = !slow_units && rs >= 12288u;
         if (fast_units) hipLaunchKernelGGL(k_snr_units_fast, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, (const uint2 *)(w + L.trace), units, (uint32_t)nunits, done);
-        hipLaunchKernelGGL(k_snr_units, dim3(nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units, (uint32_t)nunits, fast_units ? (const uint32_t *)done : (const uint32_t *)nullptr);
+        // (behind the fast kernel few regions are left: a small grid strides over them -- 16 377 workgroups that look at a flag and leave took 0.39 ms)
+        hipLaunchKernelGGL(k_snr_units, dim3(fast_units && nreg > 2048u ? 2048u : nreg), dim3(64), 0, s, a.src, (uint64_t)a.n, rgplan, reg, units, (uint32_t)nunits,
+                           fast_units ? (const uint32_t *)done : (const uint32_t *)nullptr);
         hipLaunchKernelGGL(k_snr_gate, dim3(1), dim3(1), 0, s, (const RgPlan *)rgplan, plan, units, (uint64_t)a.n);
         hb_prof_end(s);
         hb_prof_begin("k_sn_dec_units", s);
