@@ -63,6 +63,9 @@ __global__ void k_rg_init_b(const RgJob *__restrict__ jobs) { const RgJob j = jo
 #ifndef RG_LEAN_PARSE
 #define RG_LEAN_PARSE 1
 #endif
+#ifndef RG_MM_RESTART
+#define RG_MM_RESTART 1024u        // tokens a re-parse walks in merge mode before it starts over and records (0: never)
+#endif
 #ifndef RG_HEADPARSE
 #define RG_HEADPARSE 0xFFFFFFFFu     // a spotted token further into its region than this is a checkpoint of the parse from the first byte, not its start (OFF: see below)
 #endif
@@ -94,7 +97,7 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
         // the region's first byte and has, as a rule, fallen onto the true chain, while a later first token may come from a stray
         // parse further up (in periodic data stray and true chains run side by side and never meet: a record overwritten by a
         // stray parse would make the correction that follows one region behind pay a full parse per region too).
-        const bool mm = !first && RFL(R->exit0) != RG_INVALID;
+        bool mm = !first && RFL(R->exit0) != RG_INVALID;
         const uint32_t exit0 = RFL(R->exit0), outlen0 = RFL(R->outlen0), rec0 = RFL(R->entry0);     // (rec0: where the recorded parse began -- see the guess rules of the Snappy parser)
         if (!mm) for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
         uint64_t si = start, wpos = 0, out = 0;
@@ -380,6 +383,22 @@ __device__ __forceinline__ void rg_parse_region(const uint8_t *__restrict__ src,
             }
             if (done) break;
             if (refat) { si = wpos + rel; continue; }
+            if (CODEC == RG_SNAPPY && RG_MM_RESTART && mm && ntok >= RG_MM_RESTART) {
+                // A re-parse that has not met the region's record after this many tokens will hardly meet it at all: that record is a stray parse's (the
+                // guess never fell onto the chain), and left as it is nobody behind this launch can use it -- the region's restart index entries / unit starts
+                // would be found by a wave walk of the whole region, everybody else idle (measured: 518 of 16 378 regions on this library's own headline
+                // frame, 0.16 ms in k_rg_index; 0.39 ms in k_snr_units on the foreign Snappy frame).  So the parse starts over from its entry and RECORDS
+                // (dense tokens, bucket entries, token store): the record is then this chain's from its first token on.  (The tokens walked so far are
+                // walked twice: ~a tenth of a region.)  Snappy only -- measured for LZ4 too and worse there: the re-parse launch lasts as long as its
+                // slowest region, and the regions that start over are the slowest (own headline frame: k_rg_index 0.38 -> 0.35 ms but the launches behind
+                // k_rg_fix 0.29 -> 0.36 and k_rg_settle 0.15 -> 0.18; the reference-written frame 7.75 -> 8.16 ms).
+                mm = false;
+                si = start; out = 0; ntok = 0; lastbk = RG_INVALID; nq = 0; wlen = 0; wpos = 0;
+                wave_sync();
+                for (uint32_t i = lane; i < RG_BUCKETS; i += 64) { uint2 t; t.x = RG_INVALID; t.y = 0; tr[RG_DENSE + i] = t; }
+                wave_sync();
+                continue;
+            }
             if (recp || (CODEC == RG_LZ4 && checkpoint != RG_INVALID && wpos + rel > checkpoint)) {
                 // the record starts over at the spotted token (bucket entries in front of it are ignored by their readers: RgRegion.entry0)
                 si = checkpoint; start = checkpoint; checkpoint = RG_INVALID;
