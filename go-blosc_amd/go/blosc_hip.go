@@ -225,7 +225,7 @@ func DecompressHIP(data []byte, typeSize int) ([]byte, error) {
 	// ~100 / ~240 GB/s device-resident at 1 GiB.  Below that size only ONE wavefront can work on it (~0.15-0.4 GB/s, measured),
 	// slower than the pure-Go decoder: those stay on the CPU unless the caller insists.  Snappy frames of other writers stay there
 	// too: the device decodes them in parallel when their encoder compressed 64 KiB blocks (golang/snappy, libsnappy: hb_snappy.hip,
-	// 170-434 GB/s at 1 GiB), but what this package's own CPU path writes (klauspost's one-block streams) may hold 4-byte offsets, which
+	// 178-437 GB/s at 1 GiB), but what this package's own CPU path writes (klauspost's one-block streams) may hold 4-byte offsets, which
 	// leave the block to one wavefront -- and a frame does not say who wrote it.  ForceDeviceDecode sends them anyway.
 	payload := int(h.NBytesComp) - HeaderSize
 	parallel := hasRestartIndex(data, h) || (Codec(h.VersionLZ) != Snappy && (payload >= 256<<10 || (payload >= 16<<10 && h.NBytesOrig >= 2<<20)))
