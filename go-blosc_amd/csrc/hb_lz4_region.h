@@ -14,8 +14,10 @@
 #define RG_SHORT    (8u << 20)
 #define RG_PWIN     4096u         // parse window: every kernel that walks tokens is bound by one wavefront's latency, so its throughput is the number
                                   // of resident waves -- 4 KiB gives k_rg_parse / k_rg_index 32 per CU (8 KiB: 17; index-less 1 GiB decode 5.1 -> 4.6 ms)
+#ifndef RG_FIXROUNDS
 #define RG_FIXROUNDS 6             // k_rg_settle launches (each iterates to a standstill; idle once settled), re-parses in between (16 until the end of round 3:
                                   // the chains of every frame measured settle in the first or second; an idle pair of launches is ~9 us; what is still moving after six goes to the last launch)
+#endif
 #define RG_FPARSERS 2             // wavefronts of the last settle launch that parse (LDS: the regions' state takes 128 KiB)
 #define RG_FLIST    64            // regions it hands them per hop
 #define RG_MAXHOPS  1024          // hops it makes at most
